@@ -1,0 +1,152 @@
+/*
+ * relate_hip.h -- C ABI of the MI355X-native all-pairs IBD HMM path (librelate_hip.so).
+ *
+ * Drop-in boundary for aalbrechtsen/relate's per-pair loop.  The reference has no plugin/FFI layer;
+ * its de-facto operator interface is relateHMM::init_globals / sgl / dinit_globals
+ * (src/relateHMM.h:58-79) called once per pair from fast_all_pairs / joblist_fast_all_pairs
+ * (src/relateHMM.cpp:3764-3785, 3851-3875), plus the objective callback handed to findmax_bfgs
+ * (src/bfgs.h:63-66).  The entry points below replace those calls with batched ones; each cites the
+ * reference interface it stands for.  INTEGRATION.md shows the binding a maintainer adds to
+ * src/relateHMM.cpp.
+ *
+ * Conventions: every function returns 0 on success or a negative RELATE_E_* code; the message is
+ * available from relate_hip_last_error().  All buffers are caller-owned host memory unless a name
+ * starts with d_.  No torch types, no global state: one handle per GPU, used from one host thread.
+ * Genotype codes are the reference's: 0 missing, 1/2/3 = 0/1/2 copies (src/relateHMM.cpp:2985-3007).
+ * Row order of posteriors follows decodek2 (src/relateHMM.cpp:1133-1137): row0 IBD2, row1 IBD1, row2 IBD0.
+ */
+#ifndef RELATE_HIP_H
+#define RELATE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RELATE_OK 0
+#define RELATE_E_ARG -1     /* bad argument / call order */
+#define RELATE_E_HIP -2     /* HIP runtime error */
+#define RELATE_E_NODEV -3   /* no usable gfx950 device */
+#define RELATE_E_NUMERIC -4 /* NaN in the recursion (the reference prints and exit(0)s, :1513-1520) */
+#define RELATE_E_NOMEM -5
+
+#define RELATE_SYS_MAX 10000000.0 /* src/conf.h:6 -- value of an infeasible objective */
+
+typedef struct relate_hip_ctx *relate_hip_t;
+
+/* Scalars of functionPars (src/types.h:232-276) after getOptions (src/filereader_and_conversions.cpp:65-91)
+ * and post_processing_of_option_pars (src/runRelate.cpp:76-101; back2 = 2*back is applied by the library). */
+typedef struct {
+  double min;          /* MAF filter: keep min < maf < 1-min                 */
+  double epsilon;      /* genotyping error rate                               */
+  double prune_val;    /* LD pruning threshold                                */
+  double alim[2];      /* bounds of a                                         */
+  double fixA_val, fixK_val;
+  double phi;          /* calculateA                                          */
+  double convTol;
+  double par[3];       /* (a,k2,k1) used when doPar                           */
+  int back;            /* LD window; back2 = 2*back                           */
+  int doPrune;
+  int LD;              /* 1 = r^2, 0 = |D| (already un-inverted, :69)         */
+  int ld_adj;          /* LD-conditioned emissions on/off                     */
+  int double_recom;
+  int fixA, fixK, calcA;
+  int timesToConverge, timesToRun;
+  int doPar;
+  int seed_mode;       /* 0: srand(seed) per pair, glibc-compatible stream (reference: seed = time(0), :1853);
+                          1: srand(seed + pair index)                          */
+  unsigned int seed;
+} relate_opts;
+
+/* Per-pair result record: what sgl returns in fullResults (src/relateHMM.cpp:3527-3572). */
+typedef struct {
+  double a, k2, k1, k0; /* kResult = {k2,k1,k0}, a                          */
+  double negloglik;     /* kLike                                            */
+  double uLike, poLike; /* like at (alim0,0,0) and (alim0,0,1), :3478-3481  */
+  int timesRun, timesConverged;
+  int nsnp;             /* SNPs kept for the pair                           */
+  int status;           /* 0 ok, RELATE_E_NUMERIC if the recursion produced NaN */
+} relate_fit;
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+/* relateHMM object construction (src/runRelate.cpp:404). device_id = HIP device ordinal. */
+int relate_hip_create(relate_hip_t *out, int device_id);
+int relate_hip_destroy(relate_hip_t h);
+const char *relate_hip_last_error(relate_hip_t h); /* h may be NULL: error of a failed create */
+
+/* ---- data set: init_globals -> pre_calc (src/relateHMM.cpp:3371-3392, 3293-3362) --------------- */
+/* geno: N x M_raw row-major (individual-major, as iMatrix data), values 0..3; pos/chr: M_raw, already
+ * sorted by (chr,pos) as mysort leaves them (src/asort.cpp:37-88). */
+int relate_hip_load(relate_hip_t h, const uint8_t *geno, int N, int M_raw, const double *pos, const int *chr,
+                    const relate_opts *opts);
+/* calcMaf + maf_stripper + [getMea + pruning3] + global MAF + snp_pair_range(back2) + emission tables.
+ * keep_out (M_raw ints, may be NULL) = pre_calc_used_list; *M_out = SNPs kept. */
+int relate_hip_precalc(relate_hip_t h, int *keep_out, int *M_out);
+/* The stripped data the reference dumps (src/relateHMM.cpp:3745-3750): geno N x M (0..3), pos[M], maf[M]
+ * (calcMaf value).  Any pointer may be NULL. */
+int relate_hip_get_stripped(relate_hip_t h, uint8_t *geno, double *pos, double *maf);
+/* hap_global (src/relateHMM.cpp:3340-3354): mea back2 x (M-1); pBA,pBa,pbA,pba back2 x M; choose_global[M]
+ * (getHighestId of the first `back` rows, -1 for SNP 0).  Any pointer may be NULL. Inspection / tests. */
+int relate_hip_get_hap(relate_hip_t h, double *mea, double *pBA, double *pBa, double *pbA, double *pba,
+                       int *choose_global);
+
+/* ---- per-pair emissions: front half of sgl (src/relateHMM.cpp:3424-3472) ------------------------ */
+/* Inspection of one pair: keep[M]; t[M] (t of each kept SNP in stripped coordinates, 0 for the first,
+ * -1 for dropped SNPs); S 3 x M row-major (row0 IBD0,row1 IBD1,row2 IBD2; 0 where dropped). */
+int relate_hip_pair_emissions(relate_hip_t h, int ind1, int ind2, int *keep, double *t, double *S);
+
+/* ---- batched kernels ----------------------------------------------------------------------------- */
+/* like() (src/relateHMM.cpp:1426-1544) for P pairs x E parameter points: params is P x E x 3 (a,k2,k1),
+ * negloglik is P x E.  This is the call issued once per optimiser round. */
+int relate_hip_like(relate_hip_t h, const int32_t *pairs /* P x 2 */, int P, const double *params, int E,
+                    double *negloglik);
+
+/* run_optimization + *_optim + findmax_bfgs (src/relateHMM.cpp:1852-1971, 1597-1849; src/bfgs.c:127-199),
+ * plus uLike/poLike, batched over pairs.  starts: optional P x timesToRun x 4 start records
+ * {a,k2,k1,unused} replacing the rand() draws of get_rand/get_start (NULL = draw per opts.seed_mode).
+ * conv_out: optional P x timesToRun x 4 = convInfo ({a,k2,k1,negloglik} per run; rows >= timesRun zero). */
+int relate_hip_fit(relate_hip_t h, const int32_t *pairs, int P, const double *starts, relate_fit *out,
+                   double *conv_out);
+
+/* decodek2 / decode (+ viterbi) (src/relateHMM.cpp:1012-1263, 1289-1420) at given parameters.
+ * params: P x 3 (a,k2,k1).  post: P x 3 x M doubles in stripped SNP coordinates, -1 where the SNP is
+ * dropped for the pair (as the .post writer prints, :126-133); may be NULL.  path: P x M int8
+ * (0 = IBD0 ... 2 = IBD2, -1 dropped); may be NULL.  nsnp_out: P ints, may be NULL. */
+int relate_hip_decode(relate_hip_t h, const int32_t *pairs, int P, const double *params, double *post,
+                      int8_t *path, int *nsnp_out);
+
+/* sgl for P pairs: fit (or doPar) then decode at the estimate -- the body of the reference's pair loop. */
+int relate_hip_run_pairs(relate_hip_t h, const int32_t *pairs, int P, const double *starts, relate_fit *out,
+                         double *post, int8_t *path);
+
+/* findmax_bfgs (src/bfgs.h:63-66) with a host callback: same L-BFGS-B state machine and numeric gradient
+ * (src/bfgs.c:12-100) that relate_hip_fit drives in batch; nbd = 2 for all variables, noisy = -1.
+ * Returns the reference's return value (-f at the optimum) through *neg_f. No GPU involved. */
+int relate_findmax_bfgs(int numpars, double *invec, double (*fun)(double *x, void *user), void *user,
+                        const double *lowbound, const double *upbound, double *neg_f);
+
+/* glibc-compatible rand() stream used for the start points (get_rand / get_start consume rand();
+ * src/relateHMM.cpp:278-293, 1546-1560).  out[i] = i-th rand() after srand(seed). */
+void relate_rand_stream(unsigned int seed, int n, int *out);
+
+/* ---- multi-GPU: contiguous pair-block partition (no data-path collective) ------------------------ */
+/* Rank r of nranks owns pairs [*begin, *end) of a list of P pairs. */
+void relate_hip_shard(int64_t P, int rank, int nranks, int64_t *begin, int64_t *end);
+
+/* ---- measurement hooks (bench.py) ----------------------------------------------------------------- */
+/* Device time in ms of the kernels launched by the last like / decode / pair_emissions-stage call,
+ * measured with hipEvents on the library's stream: out = {stage_ms, like_ms, decode_fwd_ms, decode_bwd_ms}. */
+int relate_hip_last_timings(relate_hip_t h, double *out4);
+/* Same computation as relate_hip_like / relate_hip_decode, but on the emission block staged by the
+ * previous call for the same pairs and with results left on the device: used to time kernels with
+ * inputs resident in HBM.  reps = number of back-to-back launches; ms_out = average ms per launch. */
+int relate_hip_bench_like(relate_hip_t h, const int32_t *pairs, int P, const double *params, int E, int reps,
+                          double *ms_out);
+int relate_hip_bench_decode(relate_hip_t h, const int32_t *pairs, int P, const double *params, int reps,
+                            double *ms_fwd_out, double *ms_bwd_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,278 @@
+"""ctypes binding of librelate_hip.so (include/relate_hip.h) -- plumbing for tests, bench.py and the
+multi-GPU launcher.  The product is the shared library; this module adds no numerics and has no CPU
+fallback: if the library is missing or no gfx950 device is visible, it raises.
+
+The method names mirror the reference's per-pair operator (relateHMM::init_globals / sgl,
+src/relateHMM.h:58-79): ``Relate.init_globals(...)`` then ``like`` / ``fit`` / ``decode`` / ``sgl``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librelate_hip.so")
+
+SYS_MAX = 10000000.0
+
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+i32p = C.POINTER(C.c_int32)
+u8p = C.POINTER(C.c_uint8)
+i8p = C.POINTER(C.c_int8)
+
+
+class RelateOpts(C.Structure):
+    """relate_opts of include/relate_hip.h (scalars of functionPars, src/types.h:232-276)."""
+    _fields_ = [("min", C.c_double), ("epsilon", C.c_double), ("prune_val", C.c_double), ("alim", C.c_double * 2),
+                ("fixA_val", C.c_double), ("fixK_val", C.c_double), ("phi", C.c_double), ("convTol", C.c_double),
+                ("par", C.c_double * 3), ("back", C.c_int), ("doPrune", C.c_int), ("LD", C.c_int),
+                ("ld_adj", C.c_int), ("double_recom", C.c_int), ("fixA", C.c_int), ("fixK", C.c_int),
+                ("calcA", C.c_int), ("timesToConverge", C.c_int), ("timesToRun", C.c_int), ("doPar", C.c_int),
+                ("seed_mode", C.c_int), ("seed", C.c_uint)]
+
+
+class RelateFit(C.Structure):
+    _fields_ = [("a", C.c_double), ("k2", C.c_double), ("k1", C.c_double), ("k0", C.c_double),
+                ("negloglik", C.c_double), ("uLike", C.c_double), ("poLike", C.c_double), ("timesRun", C.c_int),
+                ("timesConverged", C.c_int), ("nsnp", C.c_int), ("status", C.c_int)]
+
+
+def default_opts():
+    """setDefaultParsRun (src/runRelate.cpp:104-147)."""
+    return dict(min=0.0, epsilon=0.01, prune_val=0.2, alim0=0.001, alim1=0.15, fixA_val=0.0, fixK_val=0.0, phi=0.013,
+                convTol=0.1, par=(0.0, 0.0, 0.0), back=5, doPrune=0, LD=1, ld_adj=1, double_recom=0, fixA=0, fixK=1,
+                calcA=1, timesToConverge=2, timesToRun=3, doPar=0, seed_mode=0, seed=1234567)
+
+
+def make_opts(o):
+    d = default_opts()
+    d.update({k: v for k, v in o.items() if k in d})
+    s = RelateOpts()
+    for k in ("min", "epsilon", "prune_val", "fixA_val", "fixK_val", "phi", "convTol", "back", "doPrune", "LD",
+              "ld_adj", "double_recom", "fixA", "fixK", "calcA", "timesToConverge", "timesToRun", "doPar", "seed_mode",
+              "seed"):
+        setattr(s, k, d[k])
+    s.alim[0], s.alim[1] = d["alim0"], d["alim1"]
+    for i in range(3):
+        s.par[i] = d["par"][i]
+    return s
+
+
+_lib = None
+
+
+def load_library():
+    """Load librelate_hip.so; raises (no fallback) if it has not been built (see __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("librelate_hip.so is not built at %s: run `python -c 'import __graft_entry__ as g; "
+                           "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.relate_hip_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.relate_hip_destroy.argtypes = [vp]
+    L.relate_hip_last_error.restype = C.c_char_p
+    L.relate_hip_last_error.argtypes = [vp]
+    L.relate_hip_load.argtypes = [vp, u8p, C.c_int, C.c_int, dp, ip, C.POINTER(RelateOpts)]
+    L.relate_hip_precalc.argtypes = [vp, ip, ip]
+    L.relate_hip_get_stripped.argtypes = [vp, u8p, dp, dp]
+    L.relate_hip_get_hap.argtypes = [vp, dp, dp, dp, dp, dp, ip]
+    L.relate_hip_pair_emissions.argtypes = [vp, C.c_int, C.c_int, ip, dp, dp]
+    L.relate_hip_like.argtypes = [vp, i32p, C.c_int, dp, C.c_int, dp]
+    L.relate_hip_fit.argtypes = [vp, i32p, C.c_int, dp, C.POINTER(RelateFit), dp]
+    L.relate_hip_decode.argtypes = [vp, i32p, C.c_int, dp, dp, i8p, ip]
+    L.relate_hip_run_pairs.argtypes = [vp, i32p, C.c_int, dp, C.POINTER(RelateFit), dp, i8p]
+    L.relate_rand_stream.argtypes = [C.c_uint, C.c_int, ip]
+    L.relate_rand_stream.restype = None
+    L.relate_hip_shard.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.relate_hip_shard.restype = None
+    L.relate_hip_last_timings.argtypes = [vp, dp]
+    L.relate_hip_bench_like.argtypes = [vp, i32p, C.c_int, dp, C.c_int, C.c_int, dp]
+    L.relate_hip_bench_decode.argtypes = [vp, i32p, C.c_int, dp, C.c_int, dp, dp]
+    _lib = L
+    return L
+
+
+FINDMAX_CB = C.CFUNCTYPE(C.c_double, dp, C.c_void_p)
+
+
+def findmax_bfgs(fun, x0, lo, hi):
+    """findmax_bfgs (src/bfgs.h:63-66) on a Python callback; returns (x, -f)."""
+    L = load_library()
+    n = len(x0)
+    cb = FINDMAX_CB(lambda p, _u: float(fun(np.array([p[i] for i in range(n)]))))
+    L.relate_findmax_bfgs.argtypes = [C.c_int, dp, FINDMAX_CB, C.c_void_p, dp, dp, dp]
+    x = np.array(x0, dtype=np.float64)
+    l = np.array(lo, dtype=np.float64)
+    h = np.array(hi, dtype=np.float64)
+    nf = C.c_double(0)
+    rc = L.relate_findmax_bfgs(n, x.ctypes.data_as(dp), cb, None, l.ctypes.data_as(dp), h.ctypes.data_as(dp),
+                               C.byref(nf))
+    if rc:
+        raise RuntimeError("relate_findmax_bfgs failed: %d" % rc)
+    return x, nf.value
+
+
+def rand_stream(seed, n):
+    L = load_library()
+    out = np.zeros(n, dtype=np.int32)
+    L.relate_rand_stream(seed, n, out.ctypes.data_as(ip))
+    return out
+
+
+def shard(P, rank, nranks):
+    L = load_library()
+    b, e = C.c_int64(0), C.c_int64(0)
+    L.relate_hip_shard(P, rank, nranks, C.byref(b), C.byref(e))
+    return b.value, e.value
+
+
+class RelateError(RuntimeError):
+    pass
+
+
+class Relate:
+    """One handle = one GPU.  Mirrors relateHMM: init_globals() once, then batched sgl pieces."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        rc = self.L.relate_hip_create(C.byref(self.h), device)
+        if rc:
+            raise RelateError("relate_hip_create: %s" % self.L.relate_hip_last_error(None).decode())
+        self.M = None
+        self.N = None
+        self.opts = None
+
+    def _chk(self, rc):
+        if rc:
+            raise RelateError(self.L.relate_hip_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.L.relate_hip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- init_globals = load + pre_calc ------------------------------------------------------------
+    def init_globals(self, geno, pos, chr_, opts):
+        g = np.ascontiguousarray(geno, dtype=np.uint8)
+        p = np.ascontiguousarray(pos, dtype=np.float64)
+        c = None if chr_ is None else np.ascontiguousarray(chr_, dtype=np.int32)
+        self.opts = dict(default_opts(), **{k: v for k, v in opts.items()})
+        s = make_opts(self.opts)
+        self.N, self.Mraw = g.shape
+        self._chk(self.L.relate_hip_load(self.h, g.ctypes.data_as(u8p), g.shape[0], g.shape[1], p.ctypes.data_as(dp),
+                                         None if c is None else c.ctypes.data_as(ip), C.byref(s)))
+        keep = np.zeros(self.Mraw, dtype=np.int32)
+        M = C.c_int(0)
+        self._chk(self.L.relate_hip_precalc(self.h, keep.ctypes.data_as(ip), C.byref(M)))
+        self.M = M.value
+        self.keep = keep
+        return self.M
+
+    def stripped(self, want_geno=True):
+        g = np.zeros((self.N, self.M), dtype=np.uint8) if want_geno else None
+        pos = np.zeros(self.M)
+        maf = np.zeros(self.M)
+        self._chk(self.L.relate_hip_get_stripped(self.h, None if g is None else g.ctypes.data_as(u8p),
+                                                 pos.ctypes.data_as(dp), maf.ctypes.data_as(dp)))
+        return g, pos, maf
+
+    def hap_global(self):
+        B2 = 2 * self.opts["back"]
+        mea = np.zeros((B2, self.M - 1))
+        t = [np.zeros((B2, self.M)) for _ in range(4)]
+        ch = np.zeros(self.M, dtype=np.int32)
+        self._chk(self.L.relate_hip_get_hap(self.h, mea.ctypes.data_as(dp), *[x.ctypes.data_as(dp) for x in t],
+                                            ch.ctypes.data_as(ip)))
+        return dict(mea=mea, pBA=t[0], pBa=t[1], pbA=t[2], pba=t[3], choose=ch)
+
+    def pair_emissions(self, i, j):
+        keep = np.zeros(self.M, dtype=np.int32)
+        t = np.zeros(self.M)
+        S = np.zeros((3, self.M))
+        self._chk(self.L.relate_hip_pair_emissions(self.h, i, j, keep.ctypes.data_as(ip), t.ctypes.data_as(dp),
+                                                   S.ctypes.data_as(dp)))
+        return keep, t, S
+
+    @staticmethod
+    def _pairs(pairs):
+        p = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        return p, p.ctypes.data_as(i32p)
+
+    # -- batched kernels ---------------------------------------------------------------------------
+    def like(self, pairs, params):
+        """params: P x E x 3 (a,k2,k1) -> P x E negative log-likelihoods (like(), src/relateHMM.cpp:1426)."""
+        p, pp = self._pairs(pairs)
+        par = np.ascontiguousarray(params, dtype=np.float64).reshape(len(p), -1, 3)
+        out = np.zeros((len(p), par.shape[1]))
+        self._chk(self.L.relate_hip_like(self.h, pp, len(p), par.ctypes.data_as(dp), par.shape[1],
+                                         out.ctypes.data_as(dp)))
+        return out
+
+    def fit(self, pairs, starts=None, want_conv=False):
+        p, pp = self._pairs(pairs)
+        R = max(1, self.opts["timesToRun"])
+        out = (RelateFit * len(p))()
+        st = None if starts is None else np.ascontiguousarray(starts, dtype=np.float64).reshape(len(p), R, 4)
+        conv = np.zeros((len(p), R, 4)) if want_conv else None
+        self._chk(self.L.relate_hip_fit(self.h, pp, len(p), None if st is None else st.ctypes.data_as(dp), out,
+                                        None if conv is None else conv.ctypes.data_as(dp)))
+        res = [{f: getattr(o, f) for f, _ in RelateFit._fields_} for o in out]
+        return (res, conv) if want_conv else res
+
+    def decode(self, pairs, params, want_post=True, want_path=False):
+        p, pp = self._pairs(pairs)
+        par = np.ascontiguousarray(params, dtype=np.float64).reshape(len(p), 3)
+        post = np.zeros((len(p), 3, self.M)) if want_post else None
+        path = np.zeros((len(p), self.M), dtype=np.int8) if want_path else None
+        ns = np.zeros(len(p), dtype=np.int32)
+        self._chk(self.L.relate_hip_decode(self.h, pp, len(p), par.ctypes.data_as(dp),
+                                           None if post is None else post.ctypes.data_as(dp),
+                                           None if path is None else path.ctypes.data_as(i8p), ns.ctypes.data_as(ip)))
+        return post, path, ns
+
+    def sgl(self, pairs, starts=None, want_post=True, want_path=False):
+        """Body of the reference's pair loop (src/relateHMM.cpp:3764-3785): fit then decode at the estimate."""
+        p, pp = self._pairs(pairs)
+        R = max(1, self.opts["timesToRun"])
+        out = (RelateFit * len(p))()
+        st = None if starts is None else np.ascontiguousarray(starts, dtype=np.float64).reshape(len(p), R, 4)
+        post = np.zeros((len(p), 3, self.M)) if want_post else None
+        path = np.zeros((len(p), self.M), dtype=np.int8) if want_path else None
+        self._chk(self.L.relate_hip_run_pairs(self.h, pp, len(p), None if st is None else st.ctypes.data_as(dp), out,
+                                              None if post is None else post.ctypes.data_as(dp),
+                                              None if path is None else path.ctypes.data_as(i8p)))
+        res = [{f: getattr(o, f) for f, _ in RelateFit._fields_} for o in out]
+        return res, post, path
+
+    # -- measurement -------------------------------------------------------------------------------
+    def timings(self):
+        t = np.zeros(4)
+        self.L.relate_hip_last_timings(self.h, t.ctypes.data_as(dp))
+        return dict(stage_ms=t[0], like_ms=t[1], decode_fwd_ms=t[2], decode_bwd_ms=t[3])
+
+    def bench_like(self, pairs, params, reps):
+        p, pp = self._pairs(pairs)
+        par = np.ascontiguousarray(params, dtype=np.float64).reshape(len(p), -1, 3)
+        ms = C.c_double(0)
+        self._chk(self.L.relate_hip_bench_like(self.h, pp, len(p), par.ctypes.data_as(dp), par.shape[1], reps,
+                                               C.byref(ms)))
+        return ms.value
+
+    def bench_decode(self, pairs, params, reps):
+        p, pp = self._pairs(pairs)
+        par = np.ascontiguousarray(params, dtype=np.float64).reshape(len(p), 3)
+        a, b = C.c_double(0), C.c_double(0)
+        self._chk(self.L.relate_hip_bench_decode(self.h, pp, len(p), par.ctypes.data_as(dp), reps, C.byref(a),
+                                                 C.byref(b)))
+        return a.value, b.value

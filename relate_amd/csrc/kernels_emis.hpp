@@ -1,0 +1,264 @@
+// Emission kernels: per-SNP shared tables (built once per data set) and the per-pair staging kernel (K4).
+// Replaces error/errorNoLD/emission2_new/errorLD/LDemission_new/LD2_new and the per-pair table
+// re-indexing remove_cross/getHighestId (src/relateHMM.cpp:2776-2975, 850-971, 481-497).  gfx950 only.
+//
+// Emission records live SNP-major in HBM: rec[s * P + p] = {t, S_ibd0, S_ibd1, S_ibd2} (32 B) for pair p
+// of the staged block; t < 0 marks a SNP dropped for that pair (a missing genotype).  Lanes of a wave hold
+// consecutive pairs, so every step reads/writes 64 x 32 B = 2 KiB contiguous.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace relate {
+
+struct __attribute__((aligned(32))) EmisRec {
+  double t, s0, s1, s2;
+};
+
+// P(observed code o in 1..3 | true genotype index tr in 0..2): error(), src/relateHMM.cpp:2828-2855.
+// The het/hom asymmetry is the reference's and is kept literally.
+__device__ __host__ inline double err_tab(int tr, int o, double eps) {
+  double a = (1 - eps) * (1 - eps), b = (1 - eps) * eps, c = eps * eps;
+  if (tr == 0) return o == 1 ? a : (o == 2 ? b : c);
+  if (tr == 1) return o == 2 ? a + c : 2 * b;
+  return o == 1 ? c : (o == 2 ? b : a);
+}
+
+// Single-SNP emission (emission2_new, :2776-2822) by its generating rule: for true genotypes (i,j) of the two
+// individuals the reference sums over the distinct orderings of {i,j} of Q(g1,g2) with
+//   IBD0: Q = D(g1) D(g2), IBD1: Q = sum_h p_h p_{g1-h} p_{g2-h}, IBD2: Q = [g1==g2] D(g1),
+// D(g) = {p^2, 2pq, q^2}; the weights are errorNoLD's products (:2861-2875).  p = freq. for genotype index 0.
+__device__ __host__ inline void emis_single(double p, double q, int o1, int o2, double eps, double *S) {
+  double D[3] = {p * p, 2 * p * q, q * q};
+  double hp[2] = {p, q};
+  double u[3], v[3];
+  for (int i = 0; i < 3; i++) {
+    u[i] = err_tab(i, o1, eps);
+    v[i] = err_tab(i, o2, eps);
+  }
+  double s0 = 0, s1 = 0, s2 = 0;
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) {
+      double w = u[a] * v[b] + (a != b ? u[b] * v[a] : 0.0);
+      double q1 = 0;
+      for (int h = 0; h <= 1; h++) {
+        int ca = a - h, cb = b - h;
+        if (ca < 0 || ca > 1 || cb < 0 || cb > 1) continue;
+        q1 += hp[h] * hp[ca] * hp[cb];
+      }
+      s0 += D[a] * D[b] * w;
+      s1 += q1 * w;
+      if (a == b) s2 += D[a] * w;
+    }
+  S[0] = s0;
+  S[1] = s1;
+  S[2] = s2;
+}
+
+// Two-SNP (LD) emission, LDemission_new (:2343-2704) by the same generating rule over two-SNP genotypes
+// g = (gc, gp) (current / conditioning SNP); hp = {pBA, pbA, pBa, pba}, index = [b at cond.] + 2*[a at cur.].
+// Wc/Wp fold errorLD's weights (:2884-2916) over the distinct orderings at each SNP separately.
+struct LdPoly {
+  double D[9];    // D[gc*3+gp]  diplotype probabilities
+  double hp[4];
+};
+
+__device__ __host__ inline void ldpoly_init(LdPoly &L, double pBA, double pbA, double pBa, double pba) {
+  L.hp[0] = pBA; L.hp[1] = pbA; L.hp[2] = pBa; L.hp[3] = pba;
+  for (int gc = 0; gc < 3; gc++)
+    for (int gp = 0; gp < 3; gp++) {
+      double s = 0;
+      for (int c1 = 0; c1 <= 1; c1++)
+        for (int p1 = 0; p1 <= 1; p1++) {
+          int c2 = gc - c1, p2 = gp - p1;
+          if (c2 < 0 || c2 > 1 || p2 < 0 || p2 > 1) continue;
+          s += L.hp[p1 + 2 * c1] * L.hp[p2 + 2 * c2];
+        }
+      L.D[gc * 3 + gp] = s;
+    }
+}
+
+__device__ __host__ inline double ldpoly_q1(const LdPoly &L, int gc1, int gp1, int gc2, int gp2) {
+  double s = 0;
+  for (int c = 0; c <= 1; c++)
+    for (int p = 0; p <= 1; p++) {
+      int c1 = gc1 - c, p1 = gp1 - p, c2 = gc2 - c, p2 = gp2 - p;
+      if (c1 < 0 || c1 > 1 || p1 < 0 || p1 > 1 || c2 < 0 || c2 > 1 || p2 < 0 || p2 > 1) continue;
+      s += L.hp[p + 2 * c] * L.hp[p1 + 2 * c1] * L.hp[p2 + 2 * c2];
+    }
+  return s;
+}
+
+__device__ __host__ inline void emis_ld(const LdPoly &L, int o1c, int o2c, int o1p, int o2p, double eps, double *S) {
+  double uc[3], vc[3], up[3], vp[3];
+  for (int i = 0; i < 3; i++) {
+    uc[i] = err_tab(i, o1c, eps);
+    vc[i] = err_tab(i, o2c, eps);
+    up[i] = err_tab(i, o1p, eps);
+    vp[i] = err_tab(i, o2p, eps);
+  }
+  double s0 = 0, s1 = 0, s2 = 0;
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) {
+      double wc = uc[a] * vc[b] + (a != b ? uc[b] * vc[a] : 0.0);
+      for (int c = 0; c < 3; c++)
+        for (int d = 0; d < 3; d++) {
+          double w = wc * (up[c] * vp[d] + (c != d ? up[d] * vp[c] : 0.0));
+          s0 += L.D[a * 3 + c] * L.D[b * 3 + d] * w;
+          s1 += ldpoly_q1(L, a, c, b, d) * w;
+          if (a == b && c == d) s2 += L.D[a * 3 + c] * w;
+        }
+    }
+  S[0] = s0;
+  S[1] = s1;
+  S[2] = s2;
+}
+
+// conditional emission of LD2_new (:2939-2975): S2 / S1t, S1t = emission2_new with p = pBA + pBa (:2948-2953)
+__device__ __host__ inline void emis_cond(double pBA, double pbA, double pBa, double pba, int o1c, int o2c, int o1p,
+                                          int o2p, double eps, double *S) {
+  LdPoly L;
+  ldpoly_init(L, pBA, pbA, pBa, pba);
+  double S2[3], S1t[3];
+  emis_ld(L, o1c, o2c, o1p, o2p, eps, S2);
+  double pc = pBA + pBa;
+  emis_single(pc, 1.0 - pc, o1p, o2p, eps, S1t);
+  S[0] = S2[0] / S1t[0];
+  S[1] = S2[1] / S1t[1];
+  S[2] = S2[2] / S1t[2];
+}
+
+// getHighestId (:481-497) on the first `back` rows of the global mea table: first strictly largest value.
+__global__ void choose_global_kernel(const double *__restrict__ mea, int M, int back, int *__restrict__ choose) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= M) return;
+  if (s == 0) { choose[0] = -1; return; }
+  int best = 0;
+  double bv = mea[s - 1];
+  for (int d = 1; d < back; d++) {
+    double v = mea[(size_t)d * (M - 1) + (s - 1)];
+    if (v > bv) { bv = v; best = d; }
+  }
+  choose[s] = best;
+}
+
+// Per-SNP tables shared by every pair.  tab1[s][o1*3+o2][3]: unconditional emission (27 doubles per SNP).
+// tabL[s][code][3], code = ((o1c*3+o2c)*3+o1p)*3+o2p with o in 0..2 (= genotype code - 1): emission of SNP s
+// conditional on SNP s-1-choose[s] (243 doubles = 1944 B per SNP; 0.97 GB at M = 5e5).
+__global__ void table_single_kernel(const double *__restrict__ maf, int M, double eps, double *__restrict__ tab1) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= M * 9) return;
+  int s = tid / 9, code = tid % 9;
+  double S[3];
+  emis_single(1.0 - maf[s], maf[s], code / 3 + 1, code % 3 + 1, eps, S);  // maf1_local = 1 - maf2_local (:3440-3441)
+  double *o = tab1 + (size_t)tid * 3;
+  o[0] = S[0]; o[1] = S[1]; o[2] = S[2];
+}
+
+__global__ void table_ld_kernel(const int *__restrict__ choose, const double *__restrict__ pBA,
+                                const double *__restrict__ pbA, const double *__restrict__ pBa,
+                                const double *__restrict__ pba, int M, double eps, double *__restrict__ tabL) {
+  long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (long)M * 81) return;
+  int s = (int)(tid / 81), code = (int)(tid % 81);
+  double S[3] = {0, 0, 0};
+  if (s > 0) {
+    size_t at = (size_t)choose[s] * M + s;
+    int o2p = code % 3, o1p = (code / 3) % 3, o2c = (code / 9) % 3, o1c = code / 27;
+    emis_cond(pBA[at], pbA[at], pBa[at], pba[at], o1c + 1, o2c + 1, o1p + 1, o2p + 1, eps, S);
+  }
+  double *o = tabL + (size_t)tid * 3;
+  o[0] = S[0]; o[1] = S[1]; o[2] = S[2];
+}
+
+__device__ inline int geno_at(const uint64_t *__restrict__ G, int W, int s, int ind) {
+  return (int)((G[(size_t)s * W + (ind >> 5)] >> (2 * (ind & 31))) & 3u);
+}
+
+// K4: front half of sgl (which_arent_NA, diff, errorNoLD/emission2_new, remove_cross, getHighestId, LD2_new;
+// src/relateHMM.cpp:3424-3472) for a block of P pairs.  One thread per (pair, chunk of `chunk` SNPs); the
+// lanes of a wave are consecutive pairs.  Fast path (no missing genotype among the previous `back` SNPs): the
+// pair's re-indexed LD table equals the global one, so the emission is a lookup in tabL.  Slow path: re-index
+// per the clean form of remove_cross (row r = r-th previous kept SNP, zero beyond depth back2), pick the row
+// with getHighestId's rule and evaluate the conditional emission directly.
+__global__ void stage_pairs_kernel(const uint64_t *__restrict__ G, int M, int W, const int32_t *__restrict__ pairs,
+                                   int P, int chunk, const double *__restrict__ pos, const double *__restrict__ tab1,
+                                   const double *__restrict__ tabL, const int *__restrict__ chooseG,
+                                   const double *__restrict__ mea, const double *__restrict__ pBA,
+                                   const double *__restrict__ pbA, const double *__restrict__ pBa,
+                                   const double *__restrict__ pba, int useLD, int back, int back2, double eps,
+                                   EmisRec *__restrict__ rec) {
+  long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int nchunk = (M + chunk - 1) / chunk;
+  if (tid >= (long)P * nchunk) return;
+  int p = (int)(tid % P), c = (int)(tid / P);
+  int i1 = pairs[2 * p], i2 = pairs[2 * p + 1];
+  int s0 = c * chunk, s1 = min(M, s0 + chunk);
+  // state at the chunk start: index of the last kept SNP before s0 (-1: none) and the number of
+  // consecutive kept SNPs immediately before s0 (saturated at back)
+  int last = -1;
+  for (int s = s0 - 1; s >= 0; s--)
+    if (geno_at(G, W, s, i1) && geno_at(G, W, s, i2)) { last = s; break; }
+  int run = 0;
+  for (int s = s0 - 1; s >= 0 && run < back; s--) {
+    if (geno_at(G, W, s, i1) && geno_at(G, W, s, i2)) run++;
+    else break;
+  }
+  for (int s = s0; s < s1; s++) {
+    int g1 = geno_at(G, W, s, i1), g2 = geno_at(G, W, s, i2);
+    EmisRec r;
+    if (g1 == 0 || g2 == 0) {
+      r.t = -1.0; r.s0 = 0; r.s1 = 0; r.s2 = 0;
+      run = 0;
+    } else {
+      if (last < 0) {
+        r.t = 0.0;  // first kept SNP: t[0] = 0 (diff, :391-404), unconditional emission (LD2_new, :2955-2957)
+      } else {
+        double d = pos[s] - pos[last];
+        r.t = d < 0 ? 10000000.0 : d;
+      }
+      if (!useLD || last < 0) {
+        const double *e = tab1 + ((size_t)s * 9 + (g1 - 1) * 3 + (g2 - 1)) * 3;
+        r.s0 = e[0]; r.s1 = e[1]; r.s2 = e[2];
+      } else if (run >= min(back, s)) {
+        int sc = s - 1 - chooseG[s];
+        int h1 = geno_at(G, W, sc, i1), h2 = geno_at(G, W, sc, i2);
+        int code = (((g1 - 1) * 3 + (g2 - 1)) * 3 + (h1 - 1)) * 3 + (h2 - 1);
+        const double *e = tabL + ((size_t)s * 81 + code) * 3;
+        r.s0 = e[0]; r.s1 = e[1]; r.s2 = e[2];
+      } else {
+        // slow path: rows r = 0..back-1 <-> r-th previous kept SNP at distance dd = s-1-s_prev (< back2)
+        int best = 0, bestS = -1, nfound = 0;
+        double bv = 0;
+        for (int dd = 0; dd < back2 && nfound < back; dd++) {
+          int sp = s - 1 - dd;
+          if (sp < 0) break;
+          if (geno_at(G, W, sp, i1) == 0 || geno_at(G, W, sp, i2) == 0) continue;
+          double v = mea[(size_t)dd * (M - 1) + (s - 1)];
+          if (nfound == 0) { bv = v; best = 0; bestS = sp; }
+          else if (v > bv) { bv = v; best = nfound; bestS = sp; }
+          nfound++;
+        }
+        if (nfound == 0) { bv = 0; bestS = -1; }
+        if (nfound < back && 0.0 > bv) bestS = -1;  // a zero-filled row beyond the window wins (getHighestId, :492)
+        if (back == 1 && nfound > 0) { /* single row: always row 0 (:484-487) */ }
+        (void)best;
+        if (bestS < 0) {
+          r.s0 = 0; r.s1 = 0; r.s2 = 0;  // hap frequencies of that row are zero -> S2 = 0
+        } else {
+          int dd = s - 1 - bestS;
+          size_t at = (size_t)dd * M + s;
+          double S[3];
+          emis_cond(pBA[at], pbA[at], pBa[at], pba[at], g1, g2, geno_at(G, W, bestS, i1), geno_at(G, W, bestS, i2),
+                    eps, S);
+          r.s0 = S[0]; r.s1 = S[1]; r.s2 = S[2];
+        }
+      }
+      last = s;
+      if (run < back) run++;
+    }
+    rec[(size_t)s * P + p] = r;
+  }
+}
+
+}  // namespace relate

@@ -1,0 +1,853 @@
+// librelate_hip.so -- C ABI (include/relate_hip.h) over the gfx950 kernels of the all-pairs IBD HMM path.
+// Host side mirrors the reference's per-pair operator relateHMM::init_globals / sgl
+// (src/relateHMM.cpp:3371-3591) as batched calls.  The product path has no CPU fallback: every numeric
+// result comes from the HIP kernels in kernels_*.hpp; host code only sequences launches and runs the
+// optimiser's control logic (fit.hpp / lbfgsb.hpp).
+#include "../../include/relate_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fit.hpp"
+#include "kernels_emis.hpp"
+#include "kernels_hmm.hpp"
+#include "kernels_precalc.hpp"
+
+using namespace relate;
+
+namespace {
+
+std::string g_create_error;
+
+template <class T>
+struct DBuf {  // grow-only device buffer
+  T *p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T));
+    if (e == hipSuccess) cap = n;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace
+
+struct relate_hip_ctx {
+  int dev = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::string err;
+  relate_opts o{};
+  int back2 = 0;
+  bool loaded = false, ready = false;
+  int N = 0, Mraw = 0, M = 0, W = 0;
+  int useLD = 0;
+  std::vector<uint8_t> h_raw;
+  std::vector<double> h_pos_raw;
+  std::vector<int> h_chr_raw;
+  std::vector<int> keep;  // Mraw: pre_calc_used_list
+  std::vector<double> h_pos, h_maf;
+  // device: data set
+  DBuf<uint64_t> dG;
+  DBuf<double> dPos, dMaf, dMea, dPBA, dPbA, dPBa, dPba, dTab1, dTabL;
+  DBuf<int> dChoose;
+  // device: staged pair block
+  DBuf<EmisRec> dRec;
+  DBuf<int32_t> dPairs;
+  std::vector<int32_t> staged;  // pairs of the block currently in dRec (2 ints per pair)
+  // device: work
+  DBuf<int32_t> dLanePair;
+  DBuf<double> dParams, dOut, dPost;
+  DBuf<Fwd3> dFwd;
+  DBuf<uint8_t> dBp;
+  DBuf<int8_t> dPath;
+  DBuf<int> dNsnp;
+  double timings[4] = {0, 0, 0, 0};
+};
+
+namespace {
+
+int fail(relate_hip_t h, int code, const std::string &msg) {
+  if (h) h->err = msg;
+  else g_create_error = msg;
+  return code;
+}
+
+#define HIPCHK(h, expr)                                                                         \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return fail(h, e_ == hipErrorOutOfMemory ? RELATE_E_NOMEM : RELATE_E_HIP,                 \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                           \
+  } while (0)
+
+inline unsigned blocks_for(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+int set_device(relate_hip_t h) {
+  HIPCHK(h, hipSetDevice(h->dev));
+  return 0;
+}
+
+size_t pair_block_limit(relate_hip_t h, size_t bytes_per_pair_snp) {
+  size_t freeb = 0, total = 0;
+  if (hipMemGetInfo(&freeb, &total) != hipSuccess) freeb = (size_t)8 << 30;
+  size_t budget = (size_t)(0.70 * (double)freeb);
+  size_t per_pair = bytes_per_pair_snp * (size_t)h->M + 256;
+  size_t lim = budget / per_pair;
+  if (lim < 1) lim = 1;
+  if (lim > ((size_t)1 << 22)) lim = (size_t)1 << 22;
+  return lim;
+}
+
+// K4 for a block of pairs (skipped when the same block is already staged)
+int stage_block(relate_hip_t h, const int32_t *pairs, int P) {
+  if ((int)h->staged.size() == 2 * P && std::memcmp(h->staged.data(), pairs, sizeof(int32_t) * 2 * P) == 0) {
+    h->timings[0] = 0;
+    return 0;
+  }
+  for (int p = 0; p < P; p++) {
+    int a = pairs[2 * p], b = pairs[2 * p + 1];
+    if (a < 0 || a >= h->N || b < 0 || b >= h->N)
+      return fail(h, RELATE_E_ARG, "pair index out of range (the data set has " + std::to_string(h->N) + " individuals)");
+  }
+  h->staged.clear();
+  HIPCHK(h, h->dRec.ensure((size_t)h->M * P));
+  HIPCHK(h, h->dPairs.ensure((size_t)2 * P));
+  HIPCHK(h, hipMemcpyAsync(h->dPairs.p, pairs, sizeof(int32_t) * 2 * P, hipMemcpyHostToDevice, h->stream));
+  const int chunk = 64;
+  long nthreads = (long)P * ((h->M + chunk - 1) / chunk);
+  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  hipLaunchKernelGGL(stage_pairs_kernel, dim3(blocks_for(nthreads, 256)), dim3(256), 0, h->stream, h->dG.p, h->M, h->W,
+                     h->dPairs.p, P, chunk, h->dPos.p, h->dTab1.p, h->dTabL.p, h->dChoose.p, h->dMea.p, h->dPBA.p,
+                     h->dPbA.p, h->dPBa.p, h->dPba.p, h->useLD, h->o.back, h->back2, h->o.epsilon, h->dRec.p);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  float ms = 0;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+  h->timings[0] = ms;
+  h->staged.assign(pairs, pairs + 2 * P);
+  return 0;
+}
+
+// K5 on the staged block: nl lanes, host arrays in, host array out
+int like_lanes(relate_hip_t h, int P, const int32_t *lane_pair, const double *params, int nl, double *out) {
+  if (nl == 0) return 0;
+  HIPCHK(h, h->dLanePair.ensure(nl));
+  HIPCHK(h, h->dParams.ensure((size_t)3 * nl));
+  HIPCHK(h, h->dOut.ensure(nl));
+  HIPCHK(h, hipMemcpyAsync(h->dLanePair.p, lane_pair, sizeof(int32_t) * nl, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->dParams.p, params, sizeof(double) * 3 * nl, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  hipLaunchKernelGGL(like_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, h->dRec.p, h->M, P,
+                     h->dLanePair.p, h->dParams.p, nl, h->o.alim[1], h->o.double_recom, h->dOut.p);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+  HIPCHK(h, hipMemcpyAsync(out, h->dOut.p, sizeof(double) * nl, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  float ms = 0;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+  h->timings[1] += ms;
+  return 0;
+}
+
+int require_ready(relate_hip_t h) {
+  if (!h) return fail(nullptr, RELATE_E_ARG, "null handle");
+  if (!h->ready) return fail(h, RELATE_E_ARG, "call relate_hip_load and relate_hip_precalc first");
+  return set_device(h);
+}
+
+// batched run_optimization for the staged block (P pairs): fills out[] and conv_out
+int fit_block(relate_hip_t h, int P, const int32_t *pairs, long pair_base, const double *starts, relate_fit *out,
+              double *conv_out) {
+  const relate_opts &o = h->o;
+  const int R = std::max(1, o.timesToRun);
+  for (int p = 0; p < P; p++) {
+    out[p] = relate_fit{};
+    out[p].status = 0;
+  }
+  // uLike / poLike (:3478-3481) ride along with the first launch
+  std::vector<int32_t> lp;
+  std::vector<double> par, val;
+  auto push = [&](int p, double a, double k2, double k1) {
+    lp.push_back(p);
+    par.push_back(a); par.push_back(k2); par.push_back(k1);
+  };
+  for (int p = 0; p < P; p++) {
+    push(p, o.alim[0], 0, 0);
+    push(p, o.alim[0], 0, 1);
+  }
+  if (o.doPar) {
+    for (int p = 0; p < P; p++) push(p, o.par[0], o.par[1], o.par[2]);
+    val.resize(lp.size());
+    int rc = like_lanes(h, P, lp.data(), par.data(), (int)lp.size(), val.data());
+    if (rc) return rc;
+    for (int p = 0; p < P; p++) {
+      out[p].uLike = val[2 * p];
+      out[p].poLike = val[2 * p + 1];
+      out[p].a = o.par[0]; out[p].k2 = o.par[1]; out[p].k1 = o.par[2];
+      out[p].k0 = 1 - out[p].k2 - out[p].k1;
+      out[p].negloglik = val[2 * P + p];
+      out[p].timesRun = 0; out[p].timesConverged = 0;
+      if (!std::isfinite(val[2 * P + p])) out[p].status = RELATE_E_NUMERIC;
+    }
+    return 0;
+  }
+  int mode = select_mode(o.fixK, o.fixA, o.calcA);
+  if (mode < 0)
+    return fail(h, RELATE_E_ARG,
+                "optimization not implemented for this fixA/fixK/calcA combination (the reference exits, "
+                "src/relateHMM.cpp:1898-1901; fixA without fixK is undefined there)");
+  FitSpec S{mode, o.fixA_val, o.fixK_val, o.phi, o.alim[0], o.alim[1]};
+  const int n = S.nvar();
+  double lo[3], hi[3];
+  mode_bounds(S, lo, hi);
+
+  struct Run {
+    FindMax fm;
+    int pair, idx;
+    std::vector<int> slot;  // for each requested point: index into val, or -1 if the wrapper short-circuits
+  };
+  std::vector<MultiStart> ms(P);
+  std::vector<GlibcRand> rng;
+  if (!starts) {
+    rng.reserve(P);
+    for (int p = 0; p < P; p++)
+      rng.emplace_back(o.seed_mode == 1 ? o.seed + (unsigned)(pair_base + p) : o.seed);
+  }
+  std::vector<std::vector<double>> results(P, std::vector<double>((size_t)R * 4, 0.0));
+  std::vector<std::vector<char>> have(P, std::vector<char>(R, 0));
+  std::vector<Run *> active;
+  for (int p = 0; p < P; p++) {
+    ms[p].timesToConverge = o.timesToConverge;
+    ms[p].timesToRun = R;
+    ms[p].convTol = o.convTol;
+  }
+  bool first_round = true;
+  for (;;) {
+    // launch the runs each pair wants
+    for (int p = 0; p < P; p++) {
+      int w = ms[p].want_to_launch();
+      for (int q = 0; q < w; q++) {
+        Run *r = new Run();
+        r->pair = p;
+        r->idx = ms[p].launched++;
+        double st[4], x0[3];
+        if (starts) std::memcpy(st, starts + ((size_t)(pair_base + p) * R + r->idx) * 4, sizeof(st));
+        else draw_start(rng[p], S, o.fixK, st);
+        start_to_x(S, st, x0);
+        r->fm.begin(n, x0, lo, hi);
+        active.push_back(r);
+      }
+    }
+    // retire finished runs, feed the multi-start rule in index order
+    bool progressed = true;
+    while (progressed) {
+      progressed = false;
+      for (size_t i = 0; i < active.size();) {
+        Run *r = active[i];
+        if (r->fm.done) {
+          x_to_result(S, r->fm.opt.x, r->fm.like, &results[r->pair][(size_t)r->idx * 4]);
+          have[r->pair][r->idx] = 1;
+          delete r;
+          active[i] = active.back();
+          active.pop_back();
+          progressed = true;
+        } else
+          i++;
+      }
+      for (int p = 0; p < P; p++)
+        while (!ms[p].finished && ms[p].consumed < ms[p].launched && have[p][ms[p].consumed])
+          ms[p].consume(&results[p][(size_t)ms[p].consumed * 4]);
+      bool relaunch = false;
+      for (int p = 0; p < P; p++)
+        if (ms[p].want_to_launch() > 0) relaunch = true;
+      if (relaunch) break;
+    }
+    bool any_want = false;
+    for (int p = 0; p < P; p++)
+      if (ms[p].want_to_launch() > 0) any_want = true;
+    if (any_want) continue;
+    if (active.empty() && !first_round) break;
+    // gather the requested points of every active run into one launch
+    if (!first_round) { lp.clear(); par.clear(); }
+    size_t base = lp.size();
+    (void)base;
+    for (Run *r : active) {
+      r->slot.assign(r->fm.npts, -1);
+      for (int q = 0; q < r->fm.npts; q++) {
+        double akk[3];
+        if (map_point(S, r->fm.pts[q], akk)) {
+          r->slot[q] = (int)lp.size();
+          push(r->pair, akk[0], akk[1], akk[2]);
+        }
+      }
+    }
+    val.resize(lp.size());
+    int rc = like_lanes(h, P, lp.data(), par.data(), (int)lp.size(), val.data());
+    if (rc) {
+      for (Run *r : active) delete r;
+      return rc;
+    }
+    if (first_round) {
+      for (int p = 0; p < P; p++) {
+        out[p].uLike = val[2 * p];
+        out[p].poLike = val[2 * p + 1];
+      }
+      first_round = false;
+    }
+    for (Run *r : active) {
+      double v[7];
+      for (int q = 0; q < r->fm.npts; q++) v[q] = r->slot[q] < 0 ? kSysMax : val[r->slot[q]];
+      bool bad = false;
+      for (int q = 0; q < r->fm.npts; q++)
+        if (!std::isfinite(v[q])) bad = true;
+      if (bad) {  // the reference prints and exit(0)s on NaN (:1513-1520); flag the pair and stop this run
+        out[r->pair].status = RELATE_E_NUMERIC;
+        r->fm.done = true;
+        r->fm.like = NAN;
+        continue;
+      }
+      r->fm.supply(v);
+    }
+    if (active.empty()) break;
+  }
+  for (int p = 0; p < P; p++) {
+    out[p].a = ms[p].best[0];
+    out[p].k2 = ms[p].best[1];
+    out[p].k1 = ms[p].best[2];
+    out[p].k0 = 1 - out[p].k2 - out[p].k1;
+    out[p].negloglik = ms[p].best[3];
+    out[p].timesRun = ms[p].consumed;
+    out[p].timesConverged = ms[p].conv;
+    if (conv_out) std::memcpy(conv_out + (size_t)(pair_base + p) * R * 4, results[p].data(), sizeof(double) * R * 4);
+  }
+  (void)pairs;
+  return 0;
+}
+
+int decode_block(relate_hip_t h, int P, const double *params, double *post, int8_t *path, int *nsnp_out,
+                 bool copy_back) {
+  const int M = h->M;
+  HIPCHK(h, h->dParams.ensure((size_t)3 * P));
+  HIPCHK(h, h->dNsnp.ensure(P));
+  HIPCHK(h, hipMemcpyAsync(h->dParams.p, params, sizeof(double) * 3 * P, hipMemcpyHostToDevice, h->stream));
+  if (post || !copy_back) {
+    HIPCHK(h, h->dFwd.ensure((size_t)M * P));
+    HIPCHK(h, h->dPost.ensure((size_t)3 * M * P));
+    HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    hipLaunchKernelGGL(decode_fwd_kernel, dim3(blocks_for(P, 256)), dim3(256), 0, h->stream, h->dRec.p, M, P,
+                       h->dParams.p, h->o.double_recom, h->dFwd.p, h->dNsnp.p);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    hipLaunchKernelGGL(decode_bwd_kernel, dim3(blocks_for(P, 256)), dim3(256), 0, h->stream, h->dRec.p, M, P,
+                       h->dParams.p, h->o.double_recom, h->dFwd.p, h->dPost.p);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+    if (copy_back && post)
+      HIPCHK(h, hipMemcpyAsync(post, h->dPost.p, sizeof(double) * 3 * M * P, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float a = 0, b = 0;
+    HIPCHK(h, hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+    HIPCHK(h, hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
+    h->timings[2] += a;
+    h->timings[3] += b;
+  }
+  if (path) {
+    HIPCHK(h, h->dBp.ensure((size_t)M * P));
+    HIPCHK(h, h->dPath.ensure((size_t)M * P));
+    hipLaunchKernelGGL(viterbi_kernel, dim3(blocks_for(P, 256)), dim3(256), 0, h->stream, h->dRec.p, M, P,
+                       h->dParams.p, h->o.double_recom, h->dBp.p, h->dPath.p);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(path, h->dPath.p, (size_t)M * P, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  if (nsnp_out) {
+    if (!(post || !copy_back)) {  // nsnp comes from the forward sweep; run it if it has not run
+      HIPCHK(h, h->dFwd.ensure((size_t)M * P));
+      hipLaunchKernelGGL(decode_fwd_kernel, dim3(blocks_for(P, 256)), dim3(256), 0, h->stream, h->dRec.p, M, P,
+                         h->dParams.p, h->o.double_recom, h->dFwd.p, h->dNsnp.p);
+      HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipMemcpyAsync(nsnp_out, h->dNsnp.p, sizeof(int) * P, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int relate_hip_create(relate_hip_t *out, int device_id) {
+  if (!out) return fail(nullptr, RELATE_E_ARG, "null output pointer");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(nullptr, RELATE_E_NODEV,
+                std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                    " (librelate_hip has no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return fail(nullptr, RELATE_E_ARG, "device_id out of range");
+  relate_hip_ctx *h = new relate_hip_ctx();
+  h->dev = device_id;
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
+    delete h;
+    return fail(nullptr, RELATE_E_HIP, "hipSetDevice/hipStreamCreate failed");
+  }
+  for (int i = 0; i < 4; i++)
+    if (hipEventCreate(&h->ev[i]) != hipSuccess) {
+      delete h;
+      return fail(nullptr, RELATE_E_HIP, "hipEventCreate failed");
+    }
+  *out = h;
+  return RELATE_OK;
+}
+
+int relate_hip_destroy(relate_hip_t h) {
+  if (!h) return RELATE_OK;
+  (void)hipSetDevice(h->dev);
+  h->dG.release(); h->dPos.release(); h->dMaf.release(); h->dMea.release(); h->dPBA.release(); h->dPbA.release();
+  h->dPBa.release(); h->dPba.release(); h->dTab1.release(); h->dTabL.release(); h->dChoose.release();
+  h->dRec.release(); h->dPairs.release(); h->dLanePair.release(); h->dParams.release(); h->dOut.release();
+  h->dPost.release(); h->dFwd.release(); h->dBp.release(); h->dPath.release(); h->dNsnp.release();
+  for (int i = 0; i < 4; i++)
+    if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return RELATE_OK;
+}
+
+const char *relate_hip_last_error(relate_hip_t h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int relate_hip_load(relate_hip_t h, const uint8_t *geno, int N, int M_raw, const double *pos, const int *chr,
+                    const relate_opts *opts) {
+  if (!h) return fail(nullptr, RELATE_E_ARG, "null handle");
+  if (!geno || !pos || !opts || N < 2 || M_raw < 2) return fail(h, RELATE_E_ARG, "bad data set arguments");
+  if (opts->doPrune && opts->back == 0)
+    return fail(h, RELATE_E_ARG, "Must supply a back > 0, when you want to prune (src/runRelate.cpp:89-92)");
+  if (opts->back < 0) return fail(h, RELATE_E_ARG, "back must be >= 0");
+  for (size_t i = 0; i < (size_t)N * M_raw; i++)
+    if (geno[i] > 3) return fail(h, RELATE_E_ARG, "Error in genotype data: value should be between 0 and 3");
+  h->o = *opts;
+  h->back2 = 2 * opts->back;  // post_processing_of_option_pars, src/runRelate.cpp:88
+  h->N = N;
+  h->Mraw = M_raw;
+  h->W = (N + 31) / 32;
+  h->h_raw.assign(geno, geno + (size_t)N * M_raw);
+  h->h_pos_raw.assign(pos, pos + M_raw);
+  if (chr) h->h_chr_raw.assign(chr, chr + M_raw);
+  else h->h_chr_raw.assign(M_raw, -1);
+  h->loaded = true;
+  h->ready = false;
+  h->staged.clear();
+  return RELATE_OK;
+}
+
+int relate_hip_precalc(relate_hip_t h, int *keep_out, int *M_out) {
+  if (!h) return fail(nullptr, RELATE_E_ARG, "null handle");
+  if (!h->loaded) return fail(h, RELATE_E_ARG, "relate_hip_load has not been called");
+  if (set_device(h)) return RELATE_E_HIP;
+  const relate_opts &o = h->o;
+  const int N = h->N, Mraw = h->Mraw, W = h->W;
+  hipStream_t st = h->stream;
+  // raw genotypes -> device, packed SNP-major at 2 bits
+  DBuf<uint8_t> dRaw;
+  DBuf<uint64_t> dG0, dG1;
+  DBuf<double> dMaf0;
+  DBuf<int> dCols;
+  auto cleanup = [&]() { dRaw.release(); dG0.release(); dG1.release(); dMaf0.release(); dCols.release(); };
+#define PCHK(expr)                                                                                     \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) {                                                                            \
+      cleanup();                                                                                       \
+      return fail(h, e_ == hipErrorOutOfMemory ? RELATE_E_NOMEM : RELATE_E_HIP,                        \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                                  \
+    }                                                                                                  \
+  } while (0)
+  PCHK(dRaw.ensure((size_t)N * Mraw));
+  PCHK(hipMemcpyAsync(dRaw.p, h->h_raw.data(), (size_t)N * Mraw, hipMemcpyHostToDevice, st));
+  PCHK(dG0.ensure((size_t)Mraw * W));
+  hipLaunchKernelGGL(pack_kernel, dim3(blocks_for((long)Mraw * W, 256)), dim3(256), 0, st, dRaw.p, N, Mraw,
+                     (const int *)nullptr, Mraw, W, dG0.p);
+  PCHK(hipGetLastError());
+  // K1 on all raw SNPs, maf_stripper on the host copy of M_raw doubles (:3302-3305)
+  PCHK(dMaf0.ensure(Mraw));
+  hipLaunchKernelGGL(maf_kernel, dim3(blocks_for(Mraw, 256)), dim3(256), 0, st, dG0.p, Mraw, W, dMaf0.p);
+  PCHK(hipGetLastError());
+  std::vector<double> maf0(Mraw);
+  PCHK(hipMemcpyAsync(maf0.data(), dMaf0.p, sizeof(double) * Mraw, hipMemcpyDeviceToHost, st));
+  PCHK(hipStreamSynchronize(st));
+  h->keep.assign(Mraw, 0);
+  std::vector<int> cols;
+  for (int s = 0; s < Mraw; s++)
+    if (maf0[s] != 0 && maf0[s] > o.min && maf0[s] < (1 - o.min)) {
+      h->keep[s] = 1;
+      cols.push_back(s);
+    }
+  if ((int)cols.size() < 2) {
+    cleanup();
+    return fail(h, RELATE_E_ARG, "fewer than 2 SNPs pass the MAF filter");
+  }
+  int M1 = (int)cols.size();
+  PCHK(dCols.ensure(Mraw));
+  PCHK(hipMemcpyAsync(dCols.p, cols.data(), sizeof(int) * M1, hipMemcpyHostToDevice, st));
+  PCHK(dG1.ensure((size_t)M1 * W));
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks_for((long)M1 * W, 256)), dim3(256), 0, st, dG0.p, dCols.p, M1, W,
+                     dG1.p);
+  PCHK(hipGetLastError());
+  const uint64_t *Gfinal = dG1.p;
+  int M = M1;
+  if (o.doPrune) {
+    // getMea (K2 at depth back) on the device, pruning3's sequential sweep on the host (:3318-3325, 669-756)
+    int B = o.back, Wd = M1 - 1;
+    DBuf<double> dMeaP;
+    PCHK(dMeaP.ensure((size_t)B * Wd));
+    PCHK(hipMemsetAsync(dMeaP.p, 0, sizeof(double) * (size_t)B * Wd, st));
+    hipLaunchKernelGGL(ld_window_kernel, dim3(blocks_for((long)M1 * B, 256)), dim3(256), 0, st, dG1.p, M1, W, B, o.LD,
+                       0, dMeaP.p, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr);
+    hipError_t le = hipGetLastError();
+    std::vector<double> mea((size_t)B * Wd);
+    if (le == hipSuccess) le = hipMemcpyAsync(mea.data(), dMeaP.p, sizeof(double) * mea.size(), hipMemcpyDeviceToHost, st);
+    if (le == hipSuccess) le = hipStreamSynchronize(st);
+    dMeaP.release();
+    PCHK(le);
+    auto MEA = [&](int r, int c) -> double & { return mea[(size_t)r * Wd + c]; };
+    std::vector<int> pk(M1, 0);
+    pk[0] = 1;
+    if (B > 1) {
+      for (int nsnp = 1; nsnp < M1; nsnp++) {
+        bool strip = false;
+        for (int r = 0; r < B; r++)
+          if (MEA(r, nsnp - 1) > o.prune_val) { strip = true; break; }
+        if (strip) {
+          pk[nsnp] = 0;
+          if (B > 2) {
+            for (int p = 0; p < B - 1; p++) {
+              if (p + nsnp >= Wd) break;
+              for (int q = p + 1; q < B - 1; q++) MEA(q, nsnp + p) = MEA(q + 1, p + nsnp);
+              MEA(B - 1, nsnp + p) = 0;
+            }
+          } else if (nsnp < Wd) {
+            MEA(1, nsnp) = 0;
+          }
+        } else
+          pk[nsnp] = 1;
+      }
+    } else {
+      for (int i = 1; i < M1; i++) pk[i] = MEA(0, i - 1) <= o.prune_val ? 1 : 0;
+    }
+    std::vector<int> rows;
+    std::vector<int> cols2;
+    for (int i = 0; i < M1; i++)
+      if (pk[i]) { rows.push_back(i); cols2.push_back(cols[i]); }
+      else h->keep[cols[i]] = 0;  // merge_bArrays, :3030-3044
+    if ((int)rows.size() < 2) {
+      cleanup();
+      return fail(h, RELATE_E_ARG, "fewer than 2 SNPs left after pruning");
+    }
+    cols.swap(cols2);
+    M = (int)rows.size();
+    PCHK(hipMemcpyAsync(dCols.p, rows.data(), sizeof(int) * M, hipMemcpyHostToDevice, st));
+    PCHK(h->dG.ensure((size_t)M * W));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks_for((long)M * W, 256)), dim3(256), 0, st, dG1.p, dCols.p, M, W,
+                       h->dG.p);
+    PCHK(hipGetLastError());
+    Gfinal = h->dG.p;
+  } else {
+    PCHK(h->dG.ensure((size_t)M * W));
+    PCHK(hipMemcpyAsync(h->dG.p, dG1.p, sizeof(uint64_t) * (size_t)M * W, hipMemcpyDeviceToDevice, st));
+    Gfinal = h->dG.p;
+  }
+  h->M = M;
+  // global MAF (calcMaf(genos_global), :3337) and positions
+  h->h_pos.resize(M);
+  for (int s = 0; s < M; s++) h->h_pos[s] = h->h_pos_raw[cols[s]];
+  PCHK(h->dPos.ensure(M));
+  PCHK(hipMemcpyAsync(h->dPos.p, h->h_pos.data(), sizeof(double) * M, hipMemcpyHostToDevice, st));
+  PCHK(h->dMaf.ensure(M));
+  hipLaunchKernelGGL(maf_kernel, dim3(blocks_for(M, 256)), dim3(256), 0, st, Gfinal, M, W, h->dMaf.p);
+  PCHK(hipGetLastError());
+  h->h_maf.resize(M);
+  PCHK(hipMemcpyAsync(h->h_maf.data(), h->dMaf.p, sizeof(double) * M, hipMemcpyDeviceToHost, st));
+  // unconditional emission table
+  PCHK(h->dTab1.ensure((size_t)M * 27));
+  hipLaunchKernelGGL(table_single_kernel, dim3(blocks_for((long)M * 9, 256)), dim3(256), 0, st, h->dMaf.p, M,
+                     o.epsilon, h->dTab1.p);
+  PCHK(hipGetLastError());
+  h->useLD = (o.ld_adj && o.back > 0) ? 1 : 0;
+  if (h->useLD) {
+    int B2 = h->back2;
+    PCHK(h->dMea.ensure((size_t)B2 * (M - 1)));
+    PCHK(h->dPBA.ensure((size_t)B2 * M));
+    PCHK(h->dPbA.ensure((size_t)B2 * M));
+    PCHK(h->dPBa.ensure((size_t)B2 * M));
+    PCHK(h->dPba.ensure((size_t)B2 * M));
+    PCHK(hipMemsetAsync(h->dMea.p, 0, sizeof(double) * (size_t)B2 * (M - 1), st));
+    PCHK(hipMemsetAsync(h->dPBA.p, 0, sizeof(double) * (size_t)B2 * M, st));
+    PCHK(hipMemsetAsync(h->dPbA.p, 0, sizeof(double) * (size_t)B2 * M, st));
+    PCHK(hipMemsetAsync(h->dPBa.p, 0, sizeof(double) * (size_t)B2 * M, st));
+    PCHK(hipMemsetAsync(h->dPba.p, 0, sizeof(double) * (size_t)B2 * M, st));
+    hipLaunchKernelGGL(ld_window_kernel, dim3(blocks_for((long)M * B2, 256)), dim3(256), 0, st, Gfinal, M, W, B2, o.LD,
+                       1, h->dMea.p, h->dPBA.p, h->dPBa.p, h->dPbA.p, h->dPba.p);
+    PCHK(hipGetLastError());
+    PCHK(h->dChoose.ensure(M));
+    hipLaunchKernelGGL(choose_global_kernel, dim3(blocks_for(M, 256)), dim3(256), 0, st, h->dMea.p, M, o.back,
+                       h->dChoose.p);
+    PCHK(hipGetLastError());
+    PCHK(h->dTabL.ensure((size_t)M * 243));
+    hipLaunchKernelGGL(table_ld_kernel, dim3(blocks_for((long)M * 81, 256)), dim3(256), 0, st, h->dChoose.p,
+                       h->dPBA.p, h->dPbA.p, h->dPBa.p, h->dPba.p, M, o.epsilon, h->dTabL.p);
+    PCHK(hipGetLastError());
+  }
+  PCHK(hipStreamSynchronize(st));
+  cleanup();
+#undef PCHK
+  h->ready = true;
+  h->staged.clear();
+  if (keep_out) std::memcpy(keep_out, h->keep.data(), sizeof(int) * Mraw);
+  if (M_out) *M_out = M;
+  return RELATE_OK;
+}
+
+int relate_hip_get_stripped(relate_hip_t h, uint8_t *geno, double *pos, double *maf) {
+  int rc = require_ready(h);
+  if (rc) return rc;
+  if (pos) std::memcpy(pos, h->h_pos.data(), sizeof(double) * h->M);
+  if (maf) std::memcpy(maf, h->h_maf.data(), sizeof(double) * h->M);
+  if (geno) {
+    DBuf<uint8_t> d;
+    HIPCHK(h, d.ensure((size_t)h->N * h->M));
+    hipLaunchKernelGGL(unpack_kernel, dim3(blocks_for((long)h->N * h->M, 256)), dim3(256), 0, h->stream, h->dG.p, h->N,
+                       h->M, h->W, d.p);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(geno, d.p, (size_t)h->N * h->M, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    d.release();
+    HIPCHK(h, e);
+  }
+  return RELATE_OK;
+}
+
+int relate_hip_get_hap(relate_hip_t h, double *mea, double *pBA, double *pBa, double *pbA, double *pba,
+                       int *choose_global) {
+  int rc = require_ready(h);
+  if (rc) return rc;
+  if (!h->useLD) return fail(h, RELATE_E_ARG, "LD tables are not built (ld_adj = 0 or back = 0)");
+  size_t nm = (size_t)h->back2 * (h->M - 1), nh = (size_t)h->back2 * h->M;
+  if (mea) HIPCHK(h, hipMemcpy(mea, h->dMea.p, sizeof(double) * nm, hipMemcpyDeviceToHost));
+  if (pBA) HIPCHK(h, hipMemcpy(pBA, h->dPBA.p, sizeof(double) * nh, hipMemcpyDeviceToHost));
+  if (pBa) HIPCHK(h, hipMemcpy(pBa, h->dPBa.p, sizeof(double) * nh, hipMemcpyDeviceToHost));
+  if (pbA) HIPCHK(h, hipMemcpy(pbA, h->dPbA.p, sizeof(double) * nh, hipMemcpyDeviceToHost));
+  if (pba) HIPCHK(h, hipMemcpy(pba, h->dPba.p, sizeof(double) * nh, hipMemcpyDeviceToHost));
+  if (choose_global) HIPCHK(h, hipMemcpy(choose_global, h->dChoose.p, sizeof(int) * h->M, hipMemcpyDeviceToHost));
+  return RELATE_OK;
+}
+
+int relate_hip_pair_emissions(relate_hip_t h, int ind1, int ind2, int *keep, double *t, double *S) {
+  int rc = require_ready(h);
+  if (rc) return rc;
+  int32_t pr[2] = {ind1, ind2};
+  rc = stage_block(h, pr, 1);
+  if (rc) return rc;
+  std::vector<EmisRec> r(h->M);
+  HIPCHK(h, hipMemcpy(r.data(), h->dRec.p, sizeof(EmisRec) * h->M, hipMemcpyDeviceToHost));
+  for (int s = 0; s < h->M; s++) {
+    bool k = r[s].t >= 0;
+    if (keep) keep[s] = k ? 1 : 0;
+    if (t) t[s] = r[s].t;
+    if (S) {
+      S[s] = k ? r[s].s0 : 0;
+      S[(size_t)h->M + s] = k ? r[s].s1 : 0;
+      S[(size_t)2 * h->M + s] = k ? r[s].s2 : 0;
+    }
+  }
+  return RELATE_OK;
+}
+
+int relate_hip_like(relate_hip_t h, const int32_t *pairs, int P, const double *params, int E, double *negloglik) {
+  int rc = require_ready(h);
+  if (rc) return rc;
+  if (!pairs || !params || !negloglik || P < 0 || E < 1) return fail(h, RELATE_E_ARG, "bad arguments");
+  h->timings[1] = 0;
+  size_t lim = pair_block_limit(h, sizeof(EmisRec));
+  std::vector<int32_t> lp;
+  for (long b0 = 0; b0 < P; b0 += (long)lim) {
+    int pb = (int)std::min<long>((long)lim, P - b0);
+    rc = stage_block(h, pairs + 2 * b0, pb);
+    if (rc) return rc;
+    lp.resize((size_t)pb * E);
+    for (int p = 0; p < pb; p++)
+      for (int e = 0; e < E; e++) lp[(size_t)p * E + e] = p;
+    rc = like_lanes(h, pb, lp.data(), params + (size_t)b0 * E * 3, pb * E, negloglik + (size_t)b0 * E);
+    if (rc) return rc;
+  }
+  return RELATE_OK;
+}
+
+int relate_hip_fit(relate_hip_t h, const int32_t *pairs, int P, const double *starts, relate_fit *out,
+                   double *conv_out) {
+  int rc = require_ready(h);
+  if (rc) return rc;
+  if (!pairs || !out || P < 0) return fail(h, RELATE_E_ARG, "bad arguments");
+  h->timings[1] = 0;
+  if (conv_out) std::memset(conv_out, 0, sizeof(double) * (size_t)P * std::max(1, h->o.timesToRun) * 4);
+  size_t lim = pair_block_limit(h, sizeof(EmisRec));
+  for (long b0 = 0; b0 < P; b0 += (long)lim) {
+    int pb = (int)std::min<long>((long)lim, P - b0);
+    rc = stage_block(h, pairs + 2 * b0, pb);
+    if (rc) return rc;
+    rc = fit_block(h, pb, pairs + 2 * b0, b0, starts, out + b0, conv_out);
+    if (rc) return rc;
+  }
+  return RELATE_OK;
+}
+
+int relate_hip_decode(relate_hip_t h, const int32_t *pairs, int P, const double *params, double *post, int8_t *path,
+                      int *nsnp_out) {
+  int rc = require_ready(h);
+  if (rc) return rc;
+  if (!pairs || !params || P < 0) return fail(h, RELATE_E_ARG, "bad arguments");
+  h->timings[2] = h->timings[3] = 0;
+  size_t lim = pair_block_limit(h, sizeof(EmisRec) + sizeof(Fwd3) + 3 * sizeof(double) + 2);
+  for (long b0 = 0; b0 < P; b0 += (long)lim) {
+    int pb = (int)std::min<long>((long)lim, P - b0);
+    rc = stage_block(h, pairs + 2 * b0, pb);
+    if (rc) return rc;
+    rc = decode_block(h, pb, params + 3 * b0, post ? post + (size_t)b0 * 3 * h->M : nullptr,
+                      path ? path + (size_t)b0 * h->M : nullptr, nsnp_out ? nsnp_out + b0 : nullptr, true);
+    if (rc) return rc;
+  }
+  return RELATE_OK;
+}
+
+int relate_hip_run_pairs(relate_hip_t h, const int32_t *pairs, int P, const double *starts, relate_fit *out,
+                         double *post, int8_t *path) {
+  int rc = require_ready(h);
+  if (rc) return rc;
+  if (!pairs || !out || P < 0) return fail(h, RELATE_E_ARG, "bad arguments");
+  h->timings[1] = h->timings[2] = h->timings[3] = 0;
+  size_t lim = pair_block_limit(h, sizeof(EmisRec) + sizeof(Fwd3) + 3 * sizeof(double) + 2);
+  std::vector<double> par;
+  std::vector<int> ns;
+  for (long b0 = 0; b0 < P; b0 += (long)lim) {
+    int pb = (int)std::min<long>((long)lim, P - b0);
+    rc = stage_block(h, pairs + 2 * b0, pb);
+    if (rc) return rc;
+    rc = fit_block(h, pb, pairs + 2 * b0, b0, starts, out + b0, nullptr);
+    if (rc) return rc;
+    par.resize((size_t)3 * pb);
+    ns.resize(pb);
+    for (int p = 0; p < pb; p++) {
+      par[3 * p] = out[b0 + p].a; par[3 * p + 1] = out[b0 + p].k2; par[3 * p + 2] = out[b0 + p].k1;
+    }
+    rc = decode_block(h, pb, par.data(), post ? post + (size_t)b0 * 3 * h->M : nullptr,
+                      path ? path + (size_t)b0 * h->M : nullptr, ns.data(), true);
+    if (rc) return rc;
+    for (int p = 0; p < pb; p++) out[b0 + p].nsnp = ns[p];
+  }
+  return RELATE_OK;
+}
+
+int relate_findmax_bfgs(int numpars, double *invec, double (*fun)(double *x, void *user), void *user,
+                        const double *lowbound, const double *upbound, double *neg_f) {
+  if (numpars < 1 || numpars > Lbfgsb::kMaxN || !invec || !fun || !lowbound || !upbound) return RELATE_E_ARG;
+  FindMax fm;
+  fm.begin(numpars, invec, lowbound, upbound);
+  while (!fm.done) {
+    double v[7];
+    for (int q = 0; q < fm.npts; q++) {
+      double x[3];
+      for (int j = 0; j < numpars; j++) x[j] = fm.pts[q][j];
+      v[q] = fun(x, user);
+    }
+    fm.supply(v);
+  }
+  for (int j = 0; j < numpars; j++) invec[j] = fm.opt.x[j];
+  if (neg_f) *neg_f = -fm.like;
+  return RELATE_OK;
+}
+
+void relate_rand_stream(unsigned int seed, int n, int *out) {
+  GlibcRand r(seed);
+  for (int i = 0; i < n; i++) out[i] = r.next();
+}
+
+void relate_hip_shard(int64_t P, int rank, int nranks, int64_t *begin, int64_t *end) {
+  if (nranks < 1) nranks = 1;
+  int64_t q = P / nranks, r = P % nranks;
+  int64_t b = rank * q + std::min<int64_t>(rank, r);
+  int64_t e = b + q + (rank < r ? 1 : 0);
+  if (begin) *begin = b;
+  if (end) *end = e;
+}
+
+int relate_hip_last_timings(relate_hip_t h, double *out4) {
+  if (!h || !out4) return RELATE_E_ARG;
+  for (int i = 0; i < 4; i++) out4[i] = h->timings[i];
+  return RELATE_OK;
+}
+
+int relate_hip_bench_like(relate_hip_t h, const int32_t *pairs, int P, const double *params, int E, int reps,
+                          double *ms_out) {
+  int rc = require_ready(h);
+  if (rc) return rc;
+  if (!pairs || !params || P < 1 || E < 1 || reps < 1) return fail(h, RELATE_E_ARG, "bad arguments");
+  rc = stage_block(h, pairs, P);
+  if (rc) return rc;
+  int nl = P * E;
+  std::vector<int32_t> lp((size_t)nl);
+  for (int p = 0; p < P; p++)
+    for (int e = 0; e < E; e++) lp[(size_t)p * E + e] = p;
+  HIPCHK(h, h->dLanePair.ensure(nl));
+  HIPCHK(h, h->dParams.ensure((size_t)3 * nl));
+  HIPCHK(h, h->dOut.ensure(nl));
+  HIPCHK(h, hipMemcpyAsync(h->dLanePair.p, lp.data(), sizeof(int32_t) * nl, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->dParams.p, params, sizeof(double) * 3 * nl, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  for (int r = 0; r < reps; r++)
+    hipLaunchKernelGGL(like_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, h->dRec.p, h->M, P,
+                       h->dLanePair.p, h->dParams.p, nl, h->o.alim[1], h->o.double_recom, h->dOut.p);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  float ms = 0;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+  if (ms_out) *ms_out = ms / reps;
+  return RELATE_OK;
+}
+
+int relate_hip_bench_decode(relate_hip_t h, const int32_t *pairs, int P, const double *params, int reps,
+                            double *ms_fwd_out, double *ms_bwd_out) {
+  int rc = require_ready(h);
+  if (rc) return rc;
+  if (!pairs || !params || P < 1 || reps < 1) return fail(h, RELATE_E_ARG, "bad arguments");
+  rc = stage_block(h, pairs, P);
+  if (rc) return rc;
+  h->timings[2] = h->timings[3] = 0;
+  for (int r = 0; r < reps; r++) {
+    rc = decode_block(h, P, params, nullptr, nullptr, nullptr, false);
+    if (rc) return rc;
+  }
+  if (ms_fwd_out) *ms_fwd_out = h->timings[2] / reps;
+  if (ms_bwd_out) *ms_bwd_out = h->timings[3] / reps;
+  return RELATE_OK;
+}
+
+}  // extern "C"

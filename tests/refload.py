@@ -9,6 +9,7 @@ Nothing here is imported by the product (relate_amd/).
 """
 import ctypes as C
 import os
+import re
 
 import numpy as np
 
@@ -45,8 +46,9 @@ def read_options(path):
         for line in fh:
             if len(vals) >= 27:
                 break
-            tok = line.split("\t")[0].strip()
-            vals.append(float(np.float32(float(tok))) if tok else 0.0)
+            tok = line.split("\t")[0]
+            mt = re.match(r"\s*[-+]?(\d+\.?\d*([eE][-+]?\d+)?|\.\d+([eE][-+]?\d+)?)", tok)  # atof semantics
+            vals.append(float(np.float32(float(mt.group(0)))) if mt else 0.0)
     o = dict(
         doAllPairs=int(vals[0]), pair=(int(vals[1]), int(vals[2])), double_recom=int(vals[3]),
         LD=1 if int(vals[4]) == 0 else 0, min=vals[5], alim0=vals[6], alim1=vals[7], doPar=int(vals[8]),
