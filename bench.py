@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- all-pairs IBD HMM hot path on MI355X: pair x SNP HMM steps per second.
+
+Workload (config.workload): the scale configuration of BASELINE.json (config 4: synthetic, 2,000 individuals x
+500,000 SNPs, all-pairs, options.all.pair.txt semantics) processed in pair blocks.  One bench *step* = one pass
+of the hot path over one block of P pairs with the genotype matrix and all per-SNP tables resident in HBM:
+    K4 stage_pairs  (per-pair emissions, front half of sgl)
+    K5 like         (forward likelihood at E parameter points per pair = what one BFGS iterate requests)
+    K6 decode       (forward + backward sweep, posteriors written to HBM)
+One HMM step = one update of the 3-state recursion for one (pair, SNP, evaluation point); a bench step therefore
+counts P * M * (E + 2) HMM steps (E forward evaluations, decode forward, decode backward).  Every rank owns a
+contiguous shard of the pair list (relate_hip_shard) and walks it block by block: weak scaling, no data-path
+collective; one RCCL all_gather of the per-pair results at the end.
+
+Launch:  python bench.py --gpus 1 --steps K --warmup W
+         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6    # vector FP64 (half the 157.3 TF FP32 vector rate)
+
+# algorithmic bytes per (pair, SNP) of one launch (DESIGN.md "Kernels"): emission record 32 B; forward vector 24 B;
+# posterior 24 B; packed genotypes 2 x 2 bit.
+BYTES = {"stage": 32.0 + 0.5, "like": 32.0, "decode_fwd": 32.0 + 24.0, "decode_bwd": 32.0 + 24.0 + 24.0}
+# FP64 operations per lane-step counted from the kernel source (2 exp at ~22 flop each + transitions + 3x3 update)
+FLOP_PER_STEP = 2 * 22 + 22 + 18
+
+
+def opts_all_pair():
+    """data/options.all.pair.txt after the reference's float parse (src/filereader_and_conversions.cpp:65-91)."""
+    f = lambda x: float(np.float32(x))  # noqa: E731
+    return dict(min=f(0.01), epsilon=f(0.01), prune_val=f(0.2), alim0=f(0.001), alim1=f(1.0), fixA_val=0.0,
+                fixK_val=0.0, phi=f(0.013), convTol=f(0.1), par=(f(0.3), 0.25, 0.5), back=5, doPrune=0, LD=1, ld_adj=1,
+                double_recom=0, fixA=0, fixK=0, calcA=1, timesToConverge=3, timesToRun=8, doPar=0, seed_mode=0,
+                seed=20240601)
+
+
+def eval_points(P, E, seed=7):
+    """E points per pair shaped like a calcA request: a centre (k2,k1) and central-difference neighbours."""
+    rng = np.random.default_rng(seed)
+    k2 = rng.uniform(0.02, 0.3, size=P)
+    k1 = rng.uniform(0.1, 0.6, size=P)
+    a = rng.uniform(0.02, 0.12, size=P)
+    par = np.empty((P, E, 3))
+    for e in range(E):
+        d = (e - E // 2) * 4.4e-6
+        par[:, e, 0] = a
+        par[:, e, 1] = k2 + (d if e % 2 else 0)
+        par[:, e, 2] = k1 + (0 if e % 2 else d)
+    return par
+
+
+def cpu_baseline(H, opt, E, want_seconds=12.0):
+    """Same hot path on the host cores for a bounded sample of the same workload (rank 0, N=1 only)."""
+    import oracleload
+    o = oracleload.Oracle()
+    ref = None
+    try:
+        import refload
+        ref = refload.Ref()
+    except Exception:  # noqa: BLE001
+        ref = None
+    gs, ps, mafs = H.stripped()
+    Ms = min(H.M, 20000)
+    gs = np.ascontiguousarray(gs[:, :Ms])
+    ps, mafs = ps[:Ms].copy(), mafs[:Ms].copy()
+    hap = o.hap_global(gs, opt["back2"], opt["LD"])  # pre-calc, not timed (the GPU's is not timed either)
+    par = eval_points(64, E)
+    steps = 0
+    t0 = time.perf_counter()
+    npairs = 0
+    for p in range(64):
+        i, j = 2 * p + 200, 2 * p + 201
+        st = o.pair_stage(gs, i, j, mafs, ps, opt["epsilon"], 1, opt["back"], opt["back2"], hap)
+        Sk = o.logs(st["S"])
+        for e in range(E):
+            if ref is not None:
+                ref.like(par[p, e], *Sk, st["t"], 0, [opt["alim0"], opt["alim1"]])
+            else:
+                o.like(par[p, e], *Sk, st["t"], 0, opt["alim1"])
+        if ref is not None:
+            ref.decode(par[p, 0], *Sk, st["t"], 0)
+        else:
+            o.decode(par[p, 0], *Sk, st["t"], 0)
+        steps += st["m"] * (E + 2)
+        npairs += 1
+        if time.perf_counter() - t0 > want_seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "pair*SNP HMM steps/s", "cores": 1,
+            "kind": "reference" if ref is not None else "port",
+            "sample": "%d pairs x first %d SNPs of the same synthetic matrix, E=%d; like/decode by %s, per-pair "
+                      "emissions by the C port; %.1f s on one core" % (
+                          npairs, Ms, E, "the compiled reference (oracle/_ref)" if ref is not None else "the C port",
+                          dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--inds", type=int, default=2000)
+    ap.add_argument("--snps", type=int, default=500000)
+    ap.add_argument("--pairs", type=int, default=2048, help="pairs per block per GPU")
+    ap.add_argument("--points", type=int, default=5, help="evaluation points per pair per like launch")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    import relate_amd
+    from relate_amd import synth
+
+    opt = opts_all_pair()
+    opt["back2"] = 2 * opt["back"]
+    t_gen = time.perf_counter()
+    geno, pos, chr_, _ = synth.make_dataset(args.inds, args.snps, device="cuda:%d" % local)
+    t_gen = time.perf_counter() - t_gen
+    H = relate_amd.Relate(local)
+    t_pre = time.perf_counter()
+    M = H.init_globals(geno, pos, chr_, opt)
+    t_pre = time.perf_counter() - t_pre
+    del geno
+
+    all_pairs = synth.all_pairs(args.inds)
+    b, e = relate_amd.shard(len(all_pairs), rank, world)
+    mine = all_pairs[b:e]
+    P, E = args.pairs, args.points
+    nblocks = (len(mine) // P)
+    if nblocks < 2:
+        raise SystemExit("shard too small for --pairs")
+    par = eval_points(P, E)
+    par1 = np.ascontiguousarray(par[:, 0, :])
+    sums = {"stage": 0.0, "like": 0.0, "decode_fwd": 0.0, "decode_bwd": 0.0}
+    lastlike = None
+
+    def step(i, record):
+        blk = mine[(i % nblocks) * P:(i % nblocks + 1) * P]
+        ms_like = H.bench_like(blk, par, 1)      # stages the block (K4) then K5
+        st_ms = H.timings()["stage_ms"]
+        f, bw = H.bench_decode(blk, par1, 1)     # K6 on the staged block
+        if record:
+            sums["stage"] += st_ms
+            sums["like"] += ms_like
+            sums["decode_fwd"] += f
+            sums["decode_bwd"] += bw
+
+    for i in range(args.warmup):
+        step(i, False)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, True)
+    if dist is not None:
+        # the path's only exchange: gather of per-pair results (here: one value per pair of the last block)
+        res = torch.zeros(P, dtype=torch.float64, device="cuda")
+        out = [torch.zeros_like(res) for _ in range(world)]
+        dist.all_gather(out, res)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        K = args.steps
+        hmm_steps = float(world) * K * P * M * (E + 2)
+        per = {k: v / K for k, v in sums.items()}  # average ms per launch, HIP events on the library's stream
+        units = {"stage": P * M, "like": P * M, "decode_fwd": P * M, "decode_bwd": P * M}
+        dom = max(per, key=per.get)
+        ach = BYTES[dom] * units[dom] / (per[dom] * 1e-3) / 1e9
+        kernel_name = {"stage": "stage_pairs_kernel", "like": "like_kernel", "decode_fwd": "decode_fwd_kernel",
+                       "decode_bwd": "decode_bwd_kernel"}[dom]
+        like_steps_s = P * M * E / (per["like"] * 1e-3)
+        line = {
+            "metric": "pair x SNP fwd-bwd HMM steps/sec (node), all-pairs", "value": hmm_steps / dt,
+            "unit": "pair*SNP HMM steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "config 4 synthetic all-pairs, pair block per step: %d individuals x %d SNPs "
+                                   "(%d after MAF filter), %d pairs/GPU/step, E=%d like points + decode, "
+                                   "options.all.pair.txt semantics (calcA, back=5)" % (args.inds, args.snps, M, P, E),
+                       "parallelism": "pair-block shards x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "note": "K5 is FP64-VALU/transcendental-bound by design (2 exp per lane-step); see "
+                                 "roofline_fp64 and DESIGN.md"},
+            "roofline_fp64": {"kernel": "like_kernel", "achieved": like_steps_s * FLOP_PER_STEP / 1e12,
+                              "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": like_steps_s * FLOP_PER_STEP / 1e12 / FP64_PEAK_TFLOPS,
+                              "lane_steps_per_s": like_steps_s},
+            "kernels_ms": per,
+            "kernels_gbs": {k: BYTES[k] * units[k] / (per[k] * 1e-3) / 1e9 for k in per},
+            "setup_s": {"synthetic_data": t_gen, "load_precalc": t_pre},
+        }
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(H, opt, E)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

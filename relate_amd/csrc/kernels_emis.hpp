@@ -3,7 +3,8 @@
 // re-indexing remove_cross/getHighestId (src/relateHMM.cpp:2776-2975, 850-971, 481-497).  gfx950 only.
 //
 // Emission records live SNP-major in HBM: rec[s * P + p] = {t, S_ibd0, S_ibd1, S_ibd2} (32 B) for pair p
-// of the staged block; t < 0 marks a SNP dropped for that pair (a missing genotype).  Lanes of a wave hold
+// of the staged block; t == -1 marks a SNP dropped for that pair (a missing genotype), t == -2 the pair's
+// first kept SNP (where the recursion starts; the reference's t[0] = 0).  Lanes of a wave hold
 // consecutive pairs, so every step reads/writes 64 x 32 B = 2 KiB contiguous.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -212,7 +213,7 @@ __global__ void stage_pairs_kernel(const uint64_t *__restrict__ G, int M, int W,
       run = 0;
     } else {
       if (last < 0) {
-        r.t = 0.0;  // first kept SNP: t[0] = 0 (diff, :391-404), unconditional emission (LD2_new, :2955-2957)
+        r.t = -2.0;  // marker: first kept SNP (t[0] = 0 in diff, :391-404; unconditional emission, LD2_new :2955-2957)
       } else {
         double d = pos[s] - pos[last];
         r.t = d < 0 ? 10000000.0 : d;

@@ -15,13 +15,13 @@ namespace relate {
 static constexpr uint64_t kLoMask = 0x5555555555555555ull;
 
 // raw: N x Mraw bytes (individual-major, as the reference's iMatrix); cols: the Msel raw column indices to
-// keep (in order); out: Msel x W packed words.  One thread per (selected SNP, word).
+// keep (in order); out: Msel x W packed words.  One thread per (word, selected SNP).
 __global__ void pack_kernel(const uint8_t *__restrict__ raw, int N, int Mraw, const int *__restrict__ cols, int Msel,
                             int W, uint64_t *__restrict__ out) {
   long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long total = (long)Msel * W;
   if (tid >= total) return;
-  int s = (int)(tid / W), w = (int)(tid % W);
+  int s = (int)(tid % Msel), w = (int)(tid / Msel);  // lanes walk consecutive SNP columns: coalesced byte reads
   int col = cols ? cols[s] : s;
   uint64_t word = 0;
   int n0 = w * 32;
@@ -31,7 +31,7 @@ __global__ void pack_kernel(const uint8_t *__restrict__ raw, int N, int Mraw, co
     uint64_t g = raw[(size_t)n * Mraw + col] & 3u;
     word |= g << (2 * b);
   }
-  out[tid] = word;
+  out[(size_t)s * W + w] = word;
 }
 
 // rows selected from an already packed matrix (pruning / MAF filter on the device copy)

@@ -77,6 +77,8 @@ struct relate_hip_ctx {
   DBuf<uint8_t> dBp;
   DBuf<int8_t> dPath;
   DBuf<int> dNsnp;
+  DBuf<double> dCm, dAstart, dBend;  // chunk products and boundary vectors of the chunked sweeps
+  DBuf<int> dCe, dCflag;
   double timings[4] = {0, 0, 0, 0};
 };
 
@@ -145,6 +147,52 @@ int stage_block(relate_hip_t h, const int32_t *pairs, int P) {
   return 0;
 }
 
+// SNP-axis chunking: enough threads to fill 256 CUs (about 6 waves per SIMD), chunks of at least 256 SNPs
+void pick_chunks(int M, long lanes, int *nchunk, int *chunk_len) {
+  const long target = 256L * 4 * 64 * 6;
+  long c = lanes > 0 ? (target + lanes - 1) / lanes : 1;
+  long cmax = std::max(1, M / 256);
+  if (c > cmax) c = cmax;
+  if (c < 1) c = 1;
+  int len = (int)((M + c - 1) / c);
+  len = (len + 7) / 8 * 8;
+  *chunk_len = len;
+  *nchunk = (M + len - 1) / len;
+}
+
+int ensure_chunk_buffers(relate_hip_t h, long n, ChunkOut *O) {
+  HIPCHK(h, h->dCm.ensure((size_t)9 * n));
+  HIPCHK(h, h->dCe.ensure((size_t)3 * n));
+  HIPCHK(h, h->dCflag.ensure((size_t)n));
+  O->m = h->dCm.p;
+  O->e = h->dCe.p;
+  O->flag = h->dCflag.p;
+  return 0;
+}
+
+// K5 launches on lanes already uploaded to dLanePair/dParams; result in dOut (device)
+int launch_like(relate_hip_t h, int P, int nl) {
+  int nchunk, clen;
+  pick_chunks(h->M, nl, &nchunk, &clen);
+  if (nchunk == 1) {
+    hipLaunchKernelGGL(like_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, h->dRec.p, h->M, P,
+                       h->dLanePair.p, h->dParams.p, nl, h->o.alim[1], h->o.double_recom, h->dOut.p);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+  }
+  long n = (long)nl * nchunk;
+  ChunkOut O;
+  int rc = ensure_chunk_buffers(h, n, &O);
+  if (rc) return rc;
+  hipLaunchKernelGGL(chunk_matrix_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, h->stream, h->dRec.p, h->M, P,
+                     h->dLanePair.p, h->dParams.p, nl, nchunk, clen, h->o.alim[1], h->o.double_recom, 1, O);
+  HIPCHK(h, hipGetLastError());
+  hipLaunchKernelGGL(like_combine_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, O, h->dParams.p, nl,
+                     nchunk, h->o.alim[1], h->dOut.p);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
 // K5 on the staged block: nl lanes, host arrays in, host array out
 int like_lanes(relate_hip_t h, int P, const int32_t *lane_pair, const double *params, int nl, double *out) {
   if (nl == 0) return 0;
@@ -154,9 +202,8 @@ int like_lanes(relate_hip_t h, int P, const int32_t *lane_pair, const double *pa
   HIPCHK(h, hipMemcpyAsync(h->dLanePair.p, lane_pair, sizeof(int32_t) * nl, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->dParams.p, params, sizeof(double) * 3 * nl, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-  hipLaunchKernelGGL(like_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, h->dRec.p, h->M, P,
-                     h->dLanePair.p, h->dParams.p, nl, h->o.alim[1], h->o.double_recom, h->dOut.p);
-  HIPCHK(h, hipGetLastError());
+  int rc = launch_like(h, P, nl);
+  if (rc) return rc;
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
   HIPCHK(h, hipMemcpyAsync(out, h->dOut.p, sizeof(double) * nl, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -341,33 +388,65 @@ int fit_block(relate_hip_t h, int P, const int32_t *pairs, long pair_base, const
   return 0;
 }
 
+// K6 launches for the staged block with params already in dParams; posteriors left in dPost
+int launch_decode(relate_hip_t h, int P) {
+  const int M = h->M;
+  int nchunk, clen;
+  pick_chunks(M, P, &nchunk, &clen);
+  long n = (long)P * nchunk;
+  const double *astart = nullptr, *bend = nullptr;
+  HIPCHK(h, hipMemsetAsync(h->dNsnp.p, 0, sizeof(int) * P, h->stream));
+  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  if (nchunk > 1) {
+    ChunkOut O;
+    int rc = ensure_chunk_buffers(h, n, &O);
+    if (rc) return rc;
+    HIPCHK(h, h->dAstart.ensure((size_t)3 * n));
+    HIPCHK(h, h->dBend.ensure((size_t)3 * n));
+    hipLaunchKernelGGL(chunk_matrix_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, h->stream, h->dRec.p, M, P,
+                       (const int32_t *)nullptr, h->dParams.p, P, nchunk, clen, h->o.alim[1], h->o.double_recom, 0, O);
+    HIPCHK(h, hipGetLastError());
+    hipLaunchKernelGGL(decode_combine_kernel, dim3(blocks_for(P, 256)), dim3(256), 0, h->stream, O, P, nchunk,
+                       h->dAstart.p, h->dBend.p);
+    HIPCHK(h, hipGetLastError());
+    astart = h->dAstart.p;
+    bend = h->dBend.p;
+  }
+  hipLaunchKernelGGL(decode_fwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, h->stream, h->dRec.p, M, P,
+                     h->dParams.p, h->o.double_recom, nchunk, clen, astart, h->dFwd.p, h->dNsnp.p);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+  hipLaunchKernelGGL(decode_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, h->stream, h->dRec.p, M, P,
+                     h->dParams.p, h->o.double_recom, nchunk, clen, bend, h->dFwd.p, h->dPost.p);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+  return 0;
+}
+
 int decode_block(relate_hip_t h, int P, const double *params, double *post, int8_t *path, int *nsnp_out,
                  bool copy_back) {
   const int M = h->M;
   HIPCHK(h, h->dParams.ensure((size_t)3 * P));
   HIPCHK(h, h->dNsnp.ensure(P));
   HIPCHK(h, hipMemcpyAsync(h->dParams.p, params, sizeof(double) * 3 * P, hipMemcpyHostToDevice, h->stream));
-  if (post || !copy_back) {
+  bool ran = false;
+  if (post || nsnp_out || !copy_back) {
     HIPCHK(h, h->dFwd.ensure((size_t)M * P));
     HIPCHK(h, h->dPost.ensure((size_t)3 * M * P));
-    HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-    hipLaunchKernelGGL(decode_fwd_kernel, dim3(blocks_for(P, 256)), dim3(256), 0, h->stream, h->dRec.p, M, P,
-                       h->dParams.p, h->o.double_recom, h->dFwd.p, h->dNsnp.p);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-    hipLaunchKernelGGL(decode_bwd_kernel, dim3(blocks_for(P, 256)), dim3(256), 0, h->stream, h->dRec.p, M, P,
-                       h->dParams.p, h->o.double_recom, h->dFwd.p, h->dPost.p);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+    int rc = launch_decode(h, P);
+    if (rc) return rc;
     if (copy_back && post)
       HIPCHK(h, hipMemcpyAsync(post, h->dPost.p, sizeof(double) * 3 * M * P, hipMemcpyDeviceToHost, h->stream));
+    if (nsnp_out) HIPCHK(h, hipMemcpyAsync(nsnp_out, h->dNsnp.p, sizeof(int) * P, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     float a = 0, b = 0;
     HIPCHK(h, hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
     HIPCHK(h, hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
     h->timings[2] += a;
     h->timings[3] += b;
+    ran = true;
   }
+  (void)ran;
   if (path) {
     HIPCHK(h, h->dBp.ensure((size_t)M * P));
     HIPCHK(h, h->dPath.ensure((size_t)M * P));
@@ -375,16 +454,6 @@ int decode_block(relate_hip_t h, int P, const double *params, double *post, int8
                        h->dParams.p, h->o.double_recom, h->dBp.p, h->dPath.p);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(path, h->dPath.p, (size_t)M * P, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-  }
-  if (nsnp_out) {
-    if (!(post || !copy_back)) {  // nsnp comes from the forward sweep; run it if it has not run
-      HIPCHK(h, h->dFwd.ensure((size_t)M * P));
-      hipLaunchKernelGGL(decode_fwd_kernel, dim3(blocks_for(P, 256)), dim3(256), 0, h->stream, h->dRec.p, M, P,
-                         h->dParams.p, h->o.double_recom, h->dFwd.p, h->dNsnp.p);
-      HIPCHK(h, hipGetLastError());
-    }
-    HIPCHK(h, hipMemcpyAsync(nsnp_out, h->dNsnp.p, sizeof(int) * P, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
   return 0;
@@ -426,6 +495,7 @@ int relate_hip_destroy(relate_hip_t h) {
   h->dPBa.release(); h->dPba.release(); h->dTab1.release(); h->dTabL.release(); h->dChoose.release();
   h->dRec.release(); h->dPairs.release(); h->dLanePair.release(); h->dParams.release(); h->dOut.release();
   h->dPost.release(); h->dFwd.release(); h->dBp.release(); h->dPath.release(); h->dNsnp.release();
+  h->dCm.release(); h->dAstart.release(); h->dBend.release(); h->dCe.release(); h->dCflag.release();
   for (int i = 0; i < 4; i++)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -669,9 +739,9 @@ int relate_hip_pair_emissions(relate_hip_t h, int ind1, int ind2, int *keep, dou
   std::vector<EmisRec> r(h->M);
   HIPCHK(h, hipMemcpy(r.data(), h->dRec.p, sizeof(EmisRec) * h->M, hipMemcpyDeviceToHost));
   for (int s = 0; s < h->M; s++) {
-    bool k = r[s].t >= 0;
+    bool k = r[s].t != -1.0;
     if (keep) keep[s] = k ? 1 : 0;
-    if (t) t[s] = r[s].t;
+    if (t) t[s] = r[s].t == -2.0 ? 0.0 : r[s].t;
     if (S) {
       S[s] = k ? r[s].s0 : 0;
       S[(size_t)h->M + s] = k ? r[s].s1 : 0;
@@ -821,10 +891,10 @@ int relate_hip_bench_like(relate_hip_t h, const int32_t *pairs, int P, const dou
   HIPCHK(h, hipMemcpyAsync(h->dLanePair.p, lp.data(), sizeof(int32_t) * nl, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->dParams.p, params, sizeof(double) * 3 * nl, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-  for (int r = 0; r < reps; r++)
-    hipLaunchKernelGGL(like_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, h->dRec.p, h->M, P,
-                       h->dLanePair.p, h->dParams.p, nl, h->o.alim[1], h->o.double_recom, h->dOut.p);
-  HIPCHK(h, hipGetLastError());
+  for (int r = 0; r < reps; r++) {
+    rc = launch_like(h, P, nl);
+    if (rc) return rc;
+  }
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   float ms = 0;
