@@ -86,6 +86,35 @@ def load_dataset(name):
     return np.ascontiguousarray(g[:, order]), np.ascontiguousarray(pos[order]), np.ascontiguousarray(chr_[order])
 
 
+def load_plink(prefix):
+    """doBimFile + bed_to_iMatrix + mysort (src/filereader_and_conversions.cpp:483-657, src/runRelate.cpp:363-381):
+    autosomes 1..22 only, positions / 1e6, .bed codes recoded {00:3, 01:missing, 10:2, 11:1}."""
+    chrs, poss = [], []
+    with open(prefix + ".bim") as fh:
+        for line in fh:
+            t = line.split()
+            if not t:
+                break
+            chrs.append(int(t[0]))
+            poss.append(float(t[3]))
+    with open(prefix + ".fam") as fh:
+        n_ind = sum(1 for line in fh if line.strip())
+    raw = np.fromfile(prefix + ".bed", dtype=np.uint8)
+    assert raw[0] == 0x6C and raw[1] == 0x1B and raw[2] == 1, "SNP-major .bed expected"
+    nsnp = len(chrs)
+    bps = (n_ind + 3) // 4
+    body = raw[3:3 + nsnp * bps].reshape(nsnp, bps)
+    codes = np.stack([(body >> (2 * k)) & 3 for k in range(4)], axis=2).reshape(nsnp, bps * 4)[:, :n_ind]
+    recode = np.array([3, 0, 2, 1], dtype=np.int32)  # recode {1,0,2,3} then 1 <-> 3 (:485, 530-533)
+    g = recode[codes].T.copy()
+    chrs = np.array(chrs, dtype=np.int32)
+    poss = np.array(poss) / 1000000
+    keep = (chrs != 0) & (chrs < 23)
+    g, chrs, poss = g[:, keep], chrs[keep], poss[keep]
+    order = np.lexsort((poss, chrs))
+    return np.ascontiguousarray(g[:, order]), np.ascontiguousarray(poss[order]), np.ascontiguousarray(chrs[order])
+
+
 def keep_pairs(path):
     """getTestIndividuals (src/filereader_and_conversions.cpp:447-474): all i<j among flagged individuals."""
     flags = read_vec(path, int)
