@@ -3,9 +3,9 @@
 // re-indexing remove_cross/getHighestId (src/relateHMM.cpp:2776-2975, 850-971, 481-497).  gfx950 only.
 //
 // Emission records live SNP-major in HBM: rec[s * P + p] = {t, S_ibd0, S_ibd1, S_ibd2} (32 B) for pair p
-// of the staged block; t == -1 marks a SNP dropped for that pair (a missing genotype), t == -2 the pair's
-// first kept SNP (where the recursion starts; the reference's t[0] = 0).  Lanes of a wave hold
-// consecutive pairs, so every step reads/writes 64 x 32 B = 2 KiB contiguous.
+// of the staged block.  A SNP dropped for that pair (a missing genotype) is {-0.0, 1, 1, 1}: an identity step
+// for the recursions, flagged by the sign bit of t; the pair's first kept SNP has t = +0.0 (the reference's
+// t[0] = 0).  Lanes of a wave hold consecutive pairs, so every step reads/writes 64 x 32 B = 2 KiB contiguous.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -209,11 +209,11 @@ __global__ void stage_pairs_kernel(const uint64_t *__restrict__ G, int M, int W,
     int g1 = geno_at(G, W, s, i1), g2 = geno_at(G, W, s, i2);
     EmisRec r;
     if (g1 == 0 || g2 == 0) {
-      r.t = -1.0; r.s0 = 0; r.s1 = 0; r.s2 = 0;
+      r.t = -0.0; r.s0 = 1; r.s1 = 1; r.s2 = 1;  // identity step; sign bit = dropped
       run = 0;
     } else {
       if (last < 0) {
-        r.t = -2.0;  // marker: first kept SNP (t[0] = 0 in diff, :391-404; unconditional emission, LD2_new :2955-2957)
+        r.t = 0.0;  // first kept SNP: t[0] = 0 in diff (:391-404); unconditional emission (LD2_new :2955-2957)
       } else {
         double d = pos[s] - pos[last];
         r.t = d < 0 ? 10000000.0 : d;

@@ -4,19 +4,29 @@
 // with per-lane parameters is not a dense contraction).
 //
 // Numerics.  The reference walks the SNPs in log space (3 exp + 6 log per step).  Here the recursion runs in the
-// linear domain and is renormalised by exact powers of two (v_frexp_exp / v_ldexp) every kRescale steps; the
-// exponent is accumulated as an integer and one log is taken at the end.  This reproduces like() to ~1e-15
-// relative (tests/test_gpu_parity.py).  The two exp() per step for e^{-a t}, e^{-a k1 t} are inherent: a is per
-// lane, t per SNP.
+// linear domain and is renormalised by exact powers of two every 8 steps; the exponent is accumulated as an
+// integer and one log is taken at the end.  The two exponentials per step (e^{-a t}, e^{-a k1 t}; a is per lane,
+// t per SNP) are inherent; they are evaluated as expm1 with a wave-uniform choice of polynomial degree, because
+// the transition matrix is affine in (e1 - 1, e2 - 1) with NO constant term off the diagonal:
+//     T01 = T21 = -k1 m1              m1 = expm1(-a t), m2 = expm1(-a k1 t)
+//     T02 = k2/(k1-1) d               d  = m2 - k1 m1
+//     T20 = k0/(k1-1) d               T10 = T01 k0/k1,  T12 = T01 k2/k1,   diagonal = 1 - row sum
+// which is the reference's T (src/relateHMM.cpp:1452-1489) with its constant terms cancelled analytically
+// (k0 + k1 + k2 = 1); the reference's own rounding noise in T02/T20 (which its fix_underflow clamps below 1e-15,
+// :542-547) does not arise.  like() is reproduced to <= 1e-13 relative (tests/test_gpu_parity.py).
 //
-// Parallelism.  One lane = one (pair, parameter point).  A pair block at M = 5e5 SNPs holds only a few thousand
-// pairs (32 B per pair and SNP), far too few lanes for 256 CUs, so the SNP axis is cut into C chunks: the
-// per-step matrices A_s = T(t_s) diag(S_s) compose associatively, chunk_matrix_kernel forms every chunk's
-// product (three row vectors with their own power-of-two exponents) in parallel, and a short combine kernel
-// folds the C products per lane.  With C = 1 the plain single-vector kernels are used.  Threads are laid out
-// chunk-major (tid = chunk * nlanes + lane): a wave reads the records of consecutive lanes of one SNP.
+// Records.  rec[s * P + p] = {t, S_ibd0, S_ibd1, S_ibd2} (32 B).  A SNP dropped for the pair is stored as
+// {-0.0, 1, 1, 1}: T(0) = I exactly, so the step is the identity and no lane ever branches on it; the sign bit
+// of t is the "dropped" flag for the kernels that must know (posterior = -1, Viterbi).  The pair's first kept SNP
+// has t = +0.0 (the reference's t[0] = 0): the start vector k passes through T(0) = I and picks up S.
 //
-// Memory.  rec[s * P + p] is 32 B; every thread streams its column with a software prefetch of kUnroll records.
+// Parallelism.  One lane = one (pair, parameter point).  When a launch has too few lanes to fill 256 CUs the SNP
+// axis is cut into C chunks: the per-step matrices A_s = T(t_s) diag(S_s) compose associatively,
+// chunk_matrix_kernel forms every chunk's product (three row vectors with their own power-of-two exponents) and a
+// short combine kernel folds the C products per lane.  The exponentials and T are shared by the three rows, so a
+// chunked step costs ~1.5x a plain one.  A workgroup is 256 lanes of ONE chunk, so loop bounds are scalar.
+//
+// Memory.  Every lane streams its column of records, 4 records (128 B) per group, double-buffered in registers.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -25,24 +35,537 @@
 
 namespace relate {
 
-static constexpr int kUnroll = 4;    // records in flight per thread
-static constexpr int kRescale = 8;   // steps between power-of-two renormalisations (emissions >~ 1e-12 per step)
+static constexpr int kGroup = 4;     // records per load group (two groups in flight)
 static constexpr double kLn2 = 0.6931471805599453094;
 
-// Per-lane transition coefficients, hoisted out of the SNP loop (src/relateHMM.cpp:1440-1490).
-struct Trans {
-  double na, nak1;           // -a, -a*k1
+// ---- expm1 for x <= 0 ------------------------------------------------------------------------------------
+__device__ inline double em_tiny(double x) {  // |x| < 2^-9: x + x^2 (1/2 + x/6 + x^2/24 + x^3/120), rel. err < 5e-17
+  double p = __builtin_fma(x, 1.0 / 120, 1.0 / 24);
+  p = __builtin_fma(x, p, 1.0 / 6);
+  p = __builtin_fma(x, p, 0.5);
+  return __builtin_fma(x * x, p, x);
+}
+__device__ inline double em_small(double x) {  // |x| < 2^-4: Taylor through x^10/10!
+  double p = 1.0 / 3628800;
+  p = __builtin_fma(x, p, 1.0 / 362880);
+  p = __builtin_fma(x, p, 1.0 / 40320);
+  p = __builtin_fma(x, p, 1.0 / 5040);
+  p = __builtin_fma(x, p, 1.0 / 720);
+  p = __builtin_fma(x, p, 1.0 / 120);
+  p = __builtin_fma(x, p, 1.0 / 24);
+  p = __builtin_fma(x, p, 1.0 / 6);
+  p = __builtin_fma(x, p, 0.5);
+  return __builtin_fma(x * x, p, x);
+}
+__device__ inline double em_general(double x) {  // any x <= 0: exp by range reduction, minus one; exact 0 below -745
+  double xc = __builtin_fmax(x, -1000.0);
+  double n = __builtin_rint(xc * 1.4426950408889634074);
+  double r = __builtin_fma(n, -6.93147180369123816490e-01, xc);
+  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;  // 1/13!
+  p = __builtin_fma(r, p, 1.0 / 479001600.0);
+  p = __builtin_fma(r, p, 1.0 / 39916800.0);
+  p = __builtin_fma(r, p, 1.0 / 3628800.0);
+  p = __builtin_fma(r, p, 1.0 / 362880.0);
+  p = __builtin_fma(r, p, 1.0 / 40320.0);
+  p = __builtin_fma(r, p, 1.0 / 5040.0);
+  p = __builtin_fma(r, p, 1.0 / 720.0);
+  p = __builtin_fma(r, p, 1.0 / 120.0);
+  p = __builtin_fma(r, p, 1.0 / 24.0);
+  p = __builtin_fma(r, p, 1.0 / 6.0);
+  p = __builtin_fma(r, p, 0.5);
+  double e = __builtin_fma(r * r, p, r) + 1.0;
+  e = __builtin_amdgcn_ldexp(e, (int)n);
+  double g = e - 1.0;
+  return (x > -0.0625) ? em_small(x) : g;  // also routes NaN to the propagating branch
+}
+
+// expm1 at a given tier: 0 = |x| < 2^-9, 1 = |x| < 2^-4, 2 = any x <= 0.  The tier is chosen per wave and per
+// group of records (lanes of a wave sit on the same SNPs, so t is uniform up to per-pair dropped SNPs and |x|
+// differs only through a, k1): straight-line code for the whole group, no per-step branch.
+template <int TIER>
+__device__ inline double em(double x) {
+  return TIER == 0 ? em_tiny(x) : (TIER == 1 ? em_small(x) : em_general(x));
+}
+
+// ---- per-lane constants, hoisted out of the SNP loop (src/relateHMM.cpp:1440-1490) -------------------------
+struct LaneC {
+  double na, nak1;  // -a, -a*k1
+  double nk1;       // -k1
+  double c02, c20;  // k2/(k1-1), k0/(k1-1); both 0 when k1 == 1 (the reference zeroes T02, T20 there)
+  double r10, r12;  // k0/k1, k2/k1; both 1 when k1 == 0
   double k0, k1, k2;
-  double c02a, c02b;         // T02 = e2*c02a + e1*c02b + k2      (zero when k1 == 1)
-  double c20a, c20b, c20c;   // T20 = e2*c20a + e1*c20b - c20c    (zero when k1 == 1)
-  double r10, r12;           // T10 = T01*r10, T12 = T01*r12      (both 1 when k1 == 0)
-  int k1_is_one, dr;
+  double tlim0, tlim1;  // t below which |a t| < 2^-9 / 2^-4
 };
 
-__device__ inline Trans make_trans(double a, double k2, double k1, double k0, int double_recom) {
-  Trans T;
-  T.na = -a;
-  T.nak1 = -a * k1;
+__device__ inline LaneC make_lane(double a, double k2, double k1, double k0) {
+  LaneC C;
+  C.na = -a;
+  C.nak1 = -a * k1;
+  C.nk1 = -k1;
+  C.k0 = k0; C.k1 = k1; C.k2 = k2;
+  C.tlim0 = 0x1p-9 / a;
+  C.tlim1 = 0x1p-4 / a;
+  double km1 = k1 - 1;
+  bool one = (k1 == 1);
+  C.c02 = one ? 0.0 : k2 / km1;
+  C.c20 = one ? 0.0 : k0 / km1;
+  if (k1 == 0) { C.r10 = 1; C.r12 = 1; } else { C.r10 = k0 / k1; C.r12 = k2 / k1; }
+  return C;
+}
+
+// the off-diagonal transition probabilities for distance t (T21 = T01)
+struct OffDiag {
+  double t01, t02, t10, t12, t20;
+};
+template <int TIER>
+__device__ inline OffDiag offdiag_at(const LaneC &C, double t) {
+  double m1 = em<TIER>(C.na * t), m2 = em<TIER>(C.nak1 * t);
+  OffDiag T;
+  T.t01 = C.nk1 * m1;
+  double d = __builtin_fma(C.nk1, m1, m2);
+  T.t02 = C.c02 * d;
+  T.t20 = C.c20 * d;
+  T.t10 = T.t01 * C.r10;
+  T.t12 = T.t01 * C.r12;
+  return T;
+}
+
+// v <- (v T) o S for NV row vectors sharing one T (forward step); DR = double recombination (dbl_recom, :501-507)
+template <int NV, bool DR, int TIER>
+__device__ inline void fwd_step(const LaneC &C, const EmisRec &r, double (&x)[NV][3]) {
+  if (DR) {
+    double m1 = em<TIER>(C.na * r.t);  // T_xy = (1 - e1) k_y + [x == y] e1
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      double F = (x[v][0] + x[v][1]) + x[v][2];
+      double g0 = __builtin_fma(-C.k0, F, x[v][0]), g1 = __builtin_fma(-C.k1, F, x[v][1]),
+             g2 = __builtin_fma(-C.k2, F, x[v][2]);
+      x[v][0] = __builtin_fma(m1, g0, x[v][0]) * r.s0;
+      x[v][1] = __builtin_fma(m1, g1, x[v][1]) * r.s1;
+      x[v][2] = __builtin_fma(m1, g2, x[v][2]) * r.s2;
+    }
+    return;
+  }
+  OffDiag T = offdiag_at<TIER>(C, r.t);
+  double a0 = T.t01 + T.t02, a1 = T.t10 + T.t12, a2 = T.t01 + T.t20;
+#pragma unroll
+  for (int v = 0; v < NV; v++) {
+    double f0 = x[v][0], f1 = x[v][1], f2 = x[v][2];
+    double u0 = __builtin_fma(f2, T.t20, __builtin_fma(f1, T.t10, __builtin_fma(-f0, a0, f0)));
+    double u1 = __builtin_fma(f0 + f2, T.t01, __builtin_fma(-f1, a1, f1));
+    double u2 = __builtin_fma(f1, T.t12, __builtin_fma(f0, T.t02, __builtin_fma(-f2, a2, f2)));
+    x[v][0] = u0 * r.s0;
+    x[v][1] = u1 * r.s1;
+    x[v][2] = u2 * r.s2;
+  }
+}
+
+// b <- T (S o b) (backward step through the record of the LATER SNP)
+template <bool DR, int TIER>
+__device__ inline void bwd_step(const LaneC &C, const EmisRec &r, double &b0, double &b1, double &b2) {
+  double q0 = r.s0 * b0, q1 = r.s1 * b1, q2 = r.s2 * b2;
+  if (DR) {
+    double m1 = em<TIER>(C.na * r.t);
+    double G = __builtin_fma(C.k2, q2, __builtin_fma(C.k1, q1, C.k0 * q0));  // sum_y k_y q_y
+    b0 = __builtin_fma(m1, q0 - G, q0);
+    b1 = __builtin_fma(m1, q1 - G, q1);
+    b2 = __builtin_fma(m1, q2 - G, q2);
+    return;
+  }
+  OffDiag T = offdiag_at<TIER>(C, r.t);
+  // n_x = q_x + sum_{y != x} T_xy (q_y - q_x)
+  double d10 = q1 - q0, d20 = q2 - q0, d21 = q2 - q1;
+  b0 = __builtin_fma(T.t02, d20, __builtin_fma(T.t01, d10, q0));
+  b1 = __builtin_fma(T.t12, d21, __builtin_fma(-T.t10, d10, q1));
+  b2 = __builtin_fma(-T.t20, d20, __builtin_fma(-T.t01, d21, q2));
+}
+
+// exact rescale of a 3-vector by a power of two; returns the exponent removed (0 for an all-zero vector)
+__device__ inline int rescale3(double &x0, double &x1, double &x2) {
+  double m = __builtin_fmax(x0, __builtin_fmax(x1, x2));
+  int e = (m > 0) ? __builtin_amdgcn_frexp_exp(m) : 0;
+  x0 = __builtin_amdgcn_ldexp(x0, -e);
+  x1 = __builtin_amdgcn_ldexp(x1, -e);
+  x2 = __builtin_amdgcn_ldexp(x2, -e);
+  return e;
+}
+
+__device__ inline bool lane_params(const double *__restrict__ params, int l, double alim1, bool reject, double &a,
+                                   double &k2, double &k1, double &k0) {
+  a = params[3 * l]; k2 = params[3 * l + 1]; k1 = params[3 * l + 2];
+  k0 = 1 - (k1 + k2);
+  return !(reject && (k2 < 0 || k1 < 0 || k0 < 0 || k2 > 1 || a > alim1));  // like()'s rejection, :1436
+}
+
+__device__ inline bool rec_dropped(const EmisRec &r) { return __builtin_signbit(r.t); }
+
+// wave-uniform tier of a group of N records: 0 if every lane has |a t| < 2^-9 for all of them, 1 if < 2^-4, else 2
+template <int N>
+__device__ inline int group_tier(const LaneC &C, const EmisRec (&R)[N]) {
+  bool t0 = true, t1 = true;
+#pragma unroll
+  for (int u = 0; u < N; u++) {
+    t0 = t0 && (R[u].t < C.tlim0);
+    t1 = t1 && (R[u].t < C.tlim1);
+  }
+  if (__all(t0)) return 0;
+  if (__all(t1)) return 1;
+  return 2;
+}
+
+template <int NV, bool DR, int TIER>
+__device__ inline void fwd_group_t(const LaneC &C, const EmisRec (&R)[kGroup], double (&x)[NV][3]) {
+#pragma unroll
+  for (int u = 0; u < kGroup; u++) fwd_step<NV, DR, TIER>(C, R[u], x);
+}
+template <int NV, bool DR>
+__device__ inline void fwd_group(const LaneC &C, const EmisRec (&R)[kGroup], double (&x)[NV][3]) {
+  int tier = group_tier<kGroup>(C, R);
+  if (tier == 0) fwd_group_t<NV, DR, 0>(C, R, x);
+  else if (tier == 1) fwd_group_t<NV, DR, 1>(C, R, x);
+  else fwd_group_t<NV, DR, 2>(C, R, x);
+}
+
+// Streams rows [sb, se) of column `col` (row stride P records) through fwd_step for NV vectors.
+template <int NV, bool DR>
+__device__ inline void sweep(const EmisRec *__restrict__ rec, int P, int lp, int sb, int se, int M, const LaneC &C,
+                             double (&x)[NV][3], int (&ex)[NV]) {
+  const size_t stride = (size_t)P;
+  const EmisRec *col = rec + lp;
+  int s = sb;
+  EmisRec A[kGroup], B[kGroup];
+  if (s + 2 * kGroup <= se) {
+#pragma unroll
+    for (int u = 0; u < kGroup; u++) A[u] = col[(size_t)(s + u) * stride];
+  }
+  for (; s + 2 * kGroup <= se; s += 2 * kGroup) {
+#pragma unroll
+    for (int u = 0; u < kGroup; u++) B[u] = col[(size_t)(s + kGroup + u) * stride];
+    fwd_group<NV, DR>(C, A, x);
+    // next group; clamped to the last row of the matrix so that a prefetch past the end (discarded) stays valid
+#pragma unroll
+    for (int u = 0; u < kGroup; u++) A[u] = col[(size_t)min(s + 2 * kGroup + u, M - 1) * stride];
+    fwd_group<NV, DR>(C, B, x);
+#pragma unroll
+    for (int v = 0; v < NV; v++) ex[v] += rescale3(x[v][0], x[v][1], x[v][2]);
+  }
+  for (; s < se; s++) {
+    EmisRec r = col[(size_t)s * stride];
+    fwd_step<NV, DR, 2>(C, r, x);
+  }
+#pragma unroll
+  for (int v = 0; v < NV; v++) ex[v] += rescale3(x[v][0], x[v][1], x[v][2]);
+}
+
+// K5, one sweep.  out[l] = -log-likelihood, SYS_MAX for a rejected point, NaN/inf if the recursion broke down.
+template <bool DR>
+__global__ void __launch_bounds__(256)
+like_kernel(const EmisRec *__restrict__ rec, int M, int P, const int32_t *__restrict__ lane_pair,
+            const double *__restrict__ params, int nlanes, double alim1, double *__restrict__ out) {
+  int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= nlanes) return;
+  double a, k2, k1, k0;
+  if (!lane_params(params, l, alim1, true, a, k2, k1, k0)) { out[l] = 10000000.0; return; }
+  LaneC C = make_lane(a, k2, k1, k0);
+  double x[1][3] = {{k0, k1, k2}};
+  int ex[1] = {0};
+  sweep<1, DR>(rec, P, lane_pair[l], 0, M, M, C, x, ex);
+  double tot = (x[0][0] + x[0][1]) + x[0][2];
+  out[l] = -(log(tot) + (double)ex[0] * kLn2);
+}
+
+// Chunk products.  Thread (chunk c, lane l) at index at = c * nlp + l (nlp = lanes padded to 256): rows X[i][.]
+// (i = unit start vector) with exponents e[i]:
+//   alpha_end[y] = sum_i alpha_start[i] X[i][y] 2^{e[i]}        beta_start[i] = 2^{e[i]} sum_y X[i][y] beta_end[y]
+// Arrays are struct-of-arrays over n = C * nlp.
+struct ChunkOut {
+  double *m;  // 9 x n
+  int *e;     // 3 x n
+};
+
+template <bool DR>
+__global__ void __launch_bounds__(256)
+chunk_matrix_kernel(const EmisRec *__restrict__ rec, int M, int P, const int32_t *__restrict__ lane_pair,
+                    const double *__restrict__ params, int nlanes, int nlp, int nchunk, int chunk_len, double alim1,
+                    int reject, ChunkOut O) {
+  int bpc = nlp / 256;  // workgroups per chunk
+  int c = blockIdx.x / bpc;
+  int l = (blockIdx.x % bpc) * 256 + threadIdx.x;
+  if (l >= nlanes) return;
+  double a, k2, k1, k0;
+  if (!lane_params(params, l, alim1, reject != 0, a, k2, k1, k0)) return;  // the combine kernel rejects the lane
+  LaneC C = make_lane(a, k2, k1, k0);
+  int sb = c * chunk_len, se = min(M, sb + chunk_len);
+  double x[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  int ex[3] = {0, 0, 0};
+  sweep<3, DR>(rec, P, lane_pair ? lane_pair[l] : l, sb, se, M, C, x, ex);
+  size_t n = (size_t)nlp * nchunk, at = (size_t)c * nlp + l;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int y = 0; y < 3; y++) O.m[(size_t)(i * 3 + y) * n + at] = x[i][y];
+    O.e[(size_t)i * n + at] = ex[i];
+  }
+}
+
+// alpha <- alpha * (chunk product); returns the exponent moved out
+__device__ inline int apply_chunk_fwd(double &f0, double &f1, double &f2, const ChunkOut &O, size_t n, size_t at) {
+  double a[3] = {f0, f1, f2};
+  int e[3] = {O.e[at], O.e[n + at], O.e[2 * n + at]};
+  int emax = -2147483647;
+  for (int i = 0; i < 3; i++)
+    if (a[i] > 0 && e[i] > emax) emax = e[i];
+  if (emax == -2147483647) { f0 = f1 = f2 = 0; return 0; }
+  double r0 = 0, r1 = 0, r2 = 0;
+  for (int i = 0; i < 3; i++) {
+    if (!(a[i] > 0)) continue;
+    double w = ldexp(a[i], e[i] - emax);
+    r0 += w * O.m[(size_t)(i * 3 + 0) * n + at];
+    r1 += w * O.m[(size_t)(i * 3 + 1) * n + at];
+    r2 += w * O.m[(size_t)(i * 3 + 2) * n + at];
+  }
+  f0 = r0; f1 = r1; f2 = r2;
+  return emax;
+}
+
+// K5 combine: folds the C chunk products of every lane into -log-likelihood.
+__global__ void __launch_bounds__(256)
+like_combine_kernel(ChunkOut O, const double *__restrict__ params, int nlanes, int nlp, int nchunk, double alim1,
+                    double *__restrict__ out) {
+  int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= nlanes) return;
+  double a, k2, k1, k0;
+  if (!lane_params(params, l, alim1, true, a, k2, k1, k0)) { out[l] = 10000000.0; return; }
+  size_t n = (size_t)nlp * nchunk;
+  double f0 = k0, f1 = k1, f2 = k2;
+  long esum = 0;
+  for (int c = 0; c < nchunk; c++) {
+    size_t at = (size_t)c * nlp + l;
+    esum += apply_chunk_fwd(f0, f1, f2, O, n, at);
+    esum += rescale3(f0, f1, f2);
+  }
+  double tot = (f0 + f1) + f2;
+  out[l] = -(log(tot) + (double)esum * kLn2);
+}
+
+// ---- K6 ----------------------------------------------------------------------------------------------------
+// Normalised forward vectors go to three planes fwd[(r * M + s) * P + p]; the boundary vectors of the chunked sweep:
+// astart[(c * nlp + p) * 3 ..] = forward vector entering chunk c, bend[...] = backward vector at the last SNP of
+// chunk c.  Any positive scale factor cancels in the posterior, so vectors are normalised with v_rcp_f64.
+__device__ inline void norm_fast(double &x0, double &x1, double &x2) {
+  double s = (x0 + x1) + x2;
+  double inv = (s > 0) ? __builtin_amdgcn_rcp(s) : 1.0;
+  x0 *= inv; x1 *= inv; x2 *= inv;
+}
+
+__global__ void __launch_bounds__(256)
+decode_combine_kernel(ChunkOut O, const double *__restrict__ params, int P, int nlp, int nchunk,
+                      double *__restrict__ astart, double *__restrict__ bend) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  size_t n = (size_t)nlp * nchunk;
+  double k2 = params[3 * p + 1], k1 = params[3 * p + 2];
+  double k0 = 1 - k2 - k1;  // decodek2, :1018
+  double f0 = k0, f1 = k1, f2 = k2;
+  for (int c = 0; c < nchunk; c++) {
+    size_t at = (size_t)c * nlp + p;
+    astart[at * 3] = f0; astart[at * 3 + 1] = f1; astart[at * 3 + 2] = f2;
+    apply_chunk_fwd(f0, f1, f2, O, n, at);
+    norm_fast(f0, f1, f2);
+  }
+  double b0 = 1, b1 = 1, b2 = 1;
+  for (int c = nchunk - 1; c >= 0; c--) {
+    size_t at = (size_t)c * nlp + p;
+    bend[at * 3] = b0; bend[at * 3 + 1] = b1; bend[at * 3 + 2] = b2;
+    // beta_start[i] = 2^{e[i]} sum_y X[i][y] beta[y]
+    double v[3];
+    int e[3], emax = -2147483647;
+    for (int i = 0; i < 3; i++) {
+      v[i] = O.m[(size_t)(i * 3 + 0) * n + at] * b0 + O.m[(size_t)(i * 3 + 1) * n + at] * b1 +
+             O.m[(size_t)(i * 3 + 2) * n + at] * b2;
+      e[i] = O.e[(size_t)i * n + at];
+      if (v[i] > 0 && e[i] > emax) emax = e[i];
+    }
+    if (emax == -2147483647) continue;
+    b0 = v[0] > 0 ? ldexp(v[0], e[0] - emax) : 0;
+    b1 = v[1] > 0 ? ldexp(v[1], e[1] - emax) : 0;
+    b2 = v[2] > 0 ? ldexp(v[2], e[2] - emax) : 0;
+    norm_fast(b0, b1, b2);
+  }
+}
+
+template <bool DR, int TIER>
+__device__ inline void dec_fwd_group(const LaneC &C, const EmisRec (&A)[kGroup], double (&x)[1][3], int &m,
+                                     double *__restrict__ o, size_t stride, size_t plane) {
+#pragma unroll
+  for (int u = 0; u < kGroup; u++) {
+    fwd_step<1, DR, TIER>(C, A[u], x);
+    norm_fast(x[0][0], x[0][1], x[0][2]);
+    m += rec_dropped(A[u]) ? 0 : 1;
+    double *q = o + (size_t)u * stride;
+    q[0] = x[0][0]; q[plane] = x[0][1]; q[2 * plane] = x[0][2];
+  }
+}
+
+// forward sweep inside one chunk; workgroup = 256 pairs of one chunk; astart == nullptr means nchunk == 1
+template <bool DR>
+__global__ void __launch_bounds__(256)
+decode_fwd_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *__restrict__ params, int nlp,
+                  int chunk_len, const double *__restrict__ astart, double *__restrict__ fwd, int *__restrict__ nsnp) {
+  int bpc = nlp / 256;
+  int c = blockIdx.x / bpc;
+  int p = (blockIdx.x % bpc) * 256 + threadIdx.x;
+  if (p >= P) return;
+  double a = params[3 * p], k2 = params[3 * p + 1], k1 = params[3 * p + 2];
+  double k0 = 1 - k2 - k1;
+  LaneC C = make_lane(a, k2, k1, k0);
+  int sb = c * chunk_len, se = min(M, sb + chunk_len);
+  double x[1][3] = {{k0, k1, k2}};
+  if (astart) {
+    size_t at = ((size_t)c * nlp + p) * 3;
+    x[0][0] = astart[at]; x[0][1] = astart[at + 1]; x[0][2] = astart[at + 2];
+  }
+  const size_t stride = (size_t)P, plane = (size_t)M * P;
+  const EmisRec *col = rec + p;
+  double *fcol = fwd + p;
+  int m = 0;
+  int s = sb;
+  EmisRec A[kGroup], B[kGroup];
+  if (s + 2 * kGroup <= se) {
+#pragma unroll
+    for (int u = 0; u < kGroup; u++) A[u] = col[(size_t)(s + u) * stride];
+  }
+  for (; s + 2 * kGroup <= se; s += 2 * kGroup) {
+#pragma unroll
+    for (int u = 0; u < kGroup; u++) B[u] = col[(size_t)(s + kGroup + u) * stride];
+    {
+      int tier = group_tier<kGroup>(C, A);
+      double *o = fcol + (size_t)s * stride;
+      if (tier == 0) dec_fwd_group<DR, 0>(C, A, x, m, o, stride, plane);
+      else if (tier == 1) dec_fwd_group<DR, 1>(C, A, x, m, o, stride, plane);
+      else dec_fwd_group<DR, 2>(C, A, x, m, o, stride, plane);
+    }
+#pragma unroll
+    for (int u = 0; u < kGroup; u++) A[u] = col[(size_t)min(s + 2 * kGroup + u, M - 1) * stride];
+    {
+      int tier = group_tier<kGroup>(C, B);
+      double *o = fcol + (size_t)(s + kGroup) * stride;
+      if (tier == 0) dec_fwd_group<DR, 0>(C, B, x, m, o, stride, plane);
+      else if (tier == 1) dec_fwd_group<DR, 1>(C, B, x, m, o, stride, plane);
+      else dec_fwd_group<DR, 2>(C, B, x, m, o, stride, plane);
+    }
+  }
+  for (; s < se; s++) {
+    EmisRec r = col[(size_t)s * stride];
+    fwd_step<1, DR, 2>(C, r, x);
+    norm_fast(x[0][0], x[0][1], x[0][2]);
+    m += rec_dropped(r) ? 0 : 1;
+    double *q = fcol + (size_t)s * stride;
+    q[0] = x[0][0]; q[plane] = x[0][1]; q[2 * plane] = x[0][2];
+  }
+  if (nsnp) atomicAdd(&nsnp[p], m);
+}
+
+// Backward sweep inside one chunk + posterior.  post is P x 3 x M (pair-major, as the host writer wants it): row0
+// IBD2, row1 IBD1, row2 IBD0 (decodek2, :1133-1137); -1 where the SNP is dropped (.post writer, :126-133).
+// posterior_x(s) = fwd_x(s) bwd_x(s) / sum_y fwd_y(s) bwd_y(s): every scale factor cancels.
+// Lanes hold consecutive pairs, whose posterior rows lie 3*M doubles apart: results of kTile SNPs are transposed
+// through LDS so that every pair row is written in 64-byte pieces.
+static constexpr int kTile = 8;
+static constexpr int kTilePad = kTile + 1;
+
+template <bool DR, int TIER>
+__device__ inline void dec_bwd_tile(const LaneC &C, const EmisRec (&R)[kTile], const double (&F)[kTile][3], int tb,
+                                    int te, double &b0, double &b1, double &b2, double (&tile)[3][256][kTilePad]) {
+#pragma unroll
+  for (int u = kTile - 1; u >= 0; u--) {
+    if (tb + u >= te) continue;  // uniform
+    double p0 = F[u][0] * b0, p1 = F[u][1] * b1, p2 = F[u][2] * b2;
+    double sum = (p0 + p1) + p2;
+    double inv = __builtin_amdgcn_rcp(sum);
+    inv = inv * __builtin_fma(-sum, inv, 2.0);
+    inv = inv * __builtin_fma(-sum, inv, 2.0);
+    bool dr = rec_dropped(R[u]);
+    tile[2][threadIdx.x][u] = dr ? -1.0 : p0 * inv;  // row2 = IBD0
+    tile[1][threadIdx.x][u] = dr ? -1.0 : p1 * inv;
+    tile[0][threadIdx.x][u] = dr ? -1.0 : p2 * inv;  // row0 = IBD2
+    bwd_step<DR, TIER>(C, R[u], b0, b1, b2);
+    norm_fast(b0, b1, b2);
+  }
+}
+
+template <bool DR>
+__global__ void __launch_bounds__(256)
+decode_bwd_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *__restrict__ params, int nlp,
+                  int chunk_len, const double *__restrict__ bend, const double *__restrict__ fwd,
+                  double *__restrict__ post) {
+  __shared__ double tile[3][256][kTilePad];
+  int bpc = nlp / 256;
+  int c = blockIdx.x / bpc;
+  int pbase = (blockIdx.x % bpc) * 256;
+  int p = pbase + threadIdx.x;
+  int pc = p < P ? p : P - 1;  // dead lanes shadow a valid pair and write nothing
+  double a = params[3 * pc], k2 = params[3 * pc + 1], k1 = params[3 * pc + 2];
+  double k0 = 1 - k2 - k1;
+  LaneC C = make_lane(a, k2, k1, k0);
+  int sb = c * chunk_len, se = min(M, sb + chunk_len);  // sb is a multiple of kTile
+  double b0 = 1, b1 = 1, b2 = 1;
+  if (bend) {
+    size_t at = ((size_t)c * nlp + pc) * 3;
+    b0 = bend[at]; b1 = bend[at + 1]; b2 = bend[at + 2];
+  }
+  const size_t stride = (size_t)P, plane = (size_t)M * P;
+  for (int tb = (se - 1) & ~(kTile - 1); tb >= sb; tb -= kTile) {
+    int te = min(se, tb + kTile);
+    EmisRec R[kTile];
+    double F[kTile][3];
+#pragma unroll
+    for (int u = 0; u < kTile; u++) {
+      int s = min(tb + u, te - 1);
+      R[u] = rec[(size_t)s * stride + pc];
+      const double *f = fwd + (size_t)s * stride + pc;
+      F[u][0] = f[0]; F[u][1] = f[plane]; F[u][2] = f[2 * plane];
+    }
+    int tier = group_tier<kTile>(C, R);
+    if (tier == 0) dec_bwd_tile<DR, 0>(C, R, F, tb, te, b0, b1, b2, tile);
+    else if (tier == 1) dec_bwd_tile<DR, 1>(C, R, F, tb, te, b0, b1, b2, tile);
+    else dec_bwd_tile<DR, 2>(C, R, F, tb, te, b0, b1, b2, tile);
+    __syncthreads();
+    // 3 x 256 x kTile values; consecutive threads write consecutive SNPs of one pair row
+#pragma unroll
+    for (int j = 0; j < 3 * kTile; j++) {
+      int idx = j * 256 + threadIdx.x;
+      int e = idx & (kTile - 1), pr = (idx >> 3) & 255, r = idx >> 11;
+      int s = tb + e, pp = pbase + pr;
+      if (s < te && pp < P) post[((size_t)pp * 3 + r) * M + s] = tile[r][pr][e];
+    }
+    __syncthreads();
+  }
+}
+
+// K7 Viterbi (:1289-1420), log domain as the reference (max3 / which_max tie rules kept, and the start quirk:
+// every state starts from max(log k) + its emission, :1356-1359).  bp: M x P bytes (3 x 2-bit back pointers).
+// The transition matrix is formed the reference's way (exp, constants, fix_underflow) because the tie rules act
+// on its logarithms.
+__device__ inline double vmax3(double a, double b, double c) {
+  if (a > b && a > c) return a;
+  else if (b > a && b > c) return b;
+  return c;
+}
+__device__ inline int vwhich3(double a, double b, double c) {
+  if (a > b && a > c) return 0;
+  else if (b > a && b > c) return 1;
+  return 2;
+}
+
+struct RefTrans {
+  double na, nak1, k0, k1, k2, c02a, c02b, c20a, c20b, c20c, r10, r12;
+  int k1_is_one, dr;
+};
+__device__ inline RefTrans make_ref_trans(double a, double k2, double k1, double k0, int double_recom) {
+  RefTrans T;
+  T.na = -a; T.nak1 = -a * k1;
   T.k0 = k0; T.k1 = k1; T.k2 = k2;
   T.k1_is_one = (k1 == 1);
   T.dr = double_recom;
@@ -55,11 +578,9 @@ __device__ inline Trans make_trans(double a, double k2, double k1, double k0, in
   if (k1 == 0) { T.r10 = 1; T.r12 = 1; } else { T.r10 = k0 / k1; T.r12 = k2 / k1; }
   return T;
 }
-
-// the nine transition probabilities T[x][y] (from state x to y) for inter-SNP distance t
-__device__ inline void trans_at(const Trans &C, double t, double (&T)[3][3]) {
+__device__ inline void ref_trans_at(const RefTrans &C, double t, double (&T)[3][3]) {
   double e1 = exp(C.na * t);
-  if (C.dr) {  // dbl_recom, :501-507
+  if (C.dr) {
     double o = 1.0 - e1;
     double b0 = o * C.k0, b1 = o * C.k1, b2 = o * C.k2;
     T[0][0] = b0 + e1; T[0][1] = b1; T[0][2] = b2;
@@ -82,393 +603,6 @@ __device__ inline void trans_at(const Trans &C, double t, double (&T)[3][3]) {
   T[2][1] = t01; T[2][0] = t20; T[2][2] = (-t01 - t20) + 1;
 }
 
-// v <- (v T) o S : one forward step of a row vector
-__device__ inline void fwd_step(double &f0, double &f1, double &f2, const double (&T)[3][3], const EmisRec &r) {
-  double n0 = (T[0][0] * f0 + T[1][0] * f1 + T[2][0] * f2) * r.s0;
-  double n1 = (T[0][1] * f0 + T[1][1] * f1 + T[2][1] * f2) * r.s1;
-  double n2 = (T[0][2] * f0 + T[1][2] * f1 + T[2][2] * f2) * r.s2;
-  f0 = n0; f1 = n1; f2 = n2;
-}
-
-// exact rescale of a 3-vector by a power of two; returns the exponent removed (0 if the vector is all zero)
-__device__ inline int rescale3(double &x0, double &x1, double &x2) {
-  double m = fmax(x0, fmax(x1, x2));
-  if (!(m > 0)) return 0;
-  int e = ilogb(m);
-  x0 = ldexp(x0, -e);
-  x1 = ldexp(x1, -e);
-  x2 = ldexp(x2, -e);
-  return e;
-}
-
-__device__ inline bool lane_params(const double *__restrict__ params, int l, double alim1, bool reject, double &a,
-                                   double &k2, double &k1, double &k0) {
-  a = params[3 * l]; k2 = params[3 * l + 1]; k1 = params[3 * l + 2];
-  k0 = 1 - (k1 + k2);
-  return !(reject && (k2 < 0 || k1 < 0 || k0 < 0 || k2 > 1 || a > alim1));  // like()'s rejection, :1436
-}
-
-// Record markers written by stage_pairs_kernel: t == kDropped: SNP dropped for the pair; t == kFirst: first kept
-// SNP of the pair (the recursion starts here from k o S).
-static constexpr double kDropped = -1.0, kFirst = -2.0;
-
-// K5, C = 1.  out[l] = -log-likelihood, SYS_MAX for a rejected point, NaN/inf if the recursion broke down.
-__global__ void __launch_bounds__(256)
-like_kernel(const EmisRec *__restrict__ rec, int M, int P, const int32_t *__restrict__ lane_pair,
-            const double *__restrict__ params, int nlanes, double alim1, int double_recom,
-            double *__restrict__ out) {
-  int l = blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= nlanes) return;
-  double a, k2, k1, k0;
-  if (!lane_params(params, l, alim1, true, a, k2, k1, k0)) { out[l] = 10000000.0; return; }
-  Trans C = make_trans(a, k2, k1, k0, double_recom);
-  const EmisRec *col = rec + lane_pair[l];
-  double f0 = 0, f1 = 0, f2 = 0;
-  long esum = 0;
-  bool started = false;
-  EmisRec nx[kUnroll];
-#pragma unroll
-  for (int u = 0; u < kUnroll; u++)
-    if (u < M) nx[u] = col[(size_t)u * P];
-  for (int s0 = 0; s0 < M; s0 += kUnroll) {
-    EmisRec cur[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; u++) cur[u] = nx[u];
-#pragma unroll
-    for (int u = 0; u < kUnroll; u++)
-      if (s0 + kUnroll + u < M) nx[u] = col[(size_t)(s0 + kUnroll + u) * P];
-#pragma unroll
-    for (int u = 0; u < kUnroll; u++) {
-      if (s0 + u >= M) break;
-      const EmisRec &r = cur[u];
-      if (r.t == kDropped) continue;
-      if (r.t == kFirst) {
-        f0 = k0 * r.s0; f1 = k1 * r.s1; f2 = k2 * r.s2;
-        started = true;
-      } else {
-        double T[3][3];
-        trans_at(C, r.t, T);
-        fwd_step(f0, f1, f2, T, r);
-      }
-    }
-    if (((s0 / kUnroll) & (kRescale / kUnroll - 1)) == 0) esum += rescale3(f0, f1, f2);
-  }
-  esum += rescale3(f0, f1, f2);
-  double tot = f0 + f1 + f2;
-  out[l] = started ? -(log(tot) + (double)esum * kLn2) : nan("");
-}
-
-// Chunk products.  For thread (chunk c, lane l): rows X[i][.] (i = unit start vector) with exponents e[i]:
-//   alpha_end[y] = sum_i alpha_start[i] * X[i][y] * 2^{e[i]}        beta_start[i] = 2^{e[i]} sum_y X[i][y] beta_end[y]
-// flag 0: matrix; 1: the chunk contains the pair's first kept SNP, row 0 is the forward VECTOR at the chunk end;
-// 2: no kept SNP in the chunk (identity).  Arrays are struct-of-arrays over n = C * nlanes threads.
-struct ChunkOut {
-  double *m;     // 9 x n
-  int *e;        // 3 x n
-  int *flag;     // n
-};
-
-__global__ void __launch_bounds__(256)
-chunk_matrix_kernel(const EmisRec *__restrict__ rec, int M, int P, const int32_t *__restrict__ lane_pair,
-                    const double *__restrict__ params, int nlanes, int nchunk, int chunk_len, double alim1,
-                    int double_recom, int reject, ChunkOut O) {
-  long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long n = (long)nlanes * nchunk;
-  if (tid >= n) return;
-  int l = (int)(tid % nlanes), c = (int)(tid / nlanes);
-  double a, k2, k1, k0;
-  if (!lane_params(params, l, alim1, reject != 0, a, k2, k1, k0)) { O.flag[tid] = 2; return; }
-  Trans C = make_trans(a, k2, k1, k0, double_recom);
-  const EmisRec *col = rec + (lane_pair ? lane_pair[l] : l);
-  int sb = c * chunk_len, se = min(M, sb + chunk_len);
-  double x[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-  int ex[3] = {0, 0, 0};
-  int flag = 2;
-  EmisRec nx[kUnroll];
-#pragma unroll
-  for (int u = 0; u < kUnroll; u++)
-    if (sb + u < se) nx[u] = col[(size_t)(sb + u) * P];
-  int it = 0;
-  for (int s0 = sb; s0 < se; s0 += kUnroll, it++) {
-    EmisRec cur[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; u++) cur[u] = nx[u];
-#pragma unroll
-    for (int u = 0; u < kUnroll; u++)
-      if (s0 + kUnroll + u < se) nx[u] = col[(size_t)(s0 + kUnroll + u) * P];
-#pragma unroll
-    for (int u = 0; u < kUnroll; u++) {
-      if (s0 + u >= se) break;
-      const EmisRec &r = cur[u];
-      if (r.t == kDropped) continue;
-      if (r.t == kFirst) {
-        x[0][0] = k0 * r.s0; x[0][1] = k1 * r.s1; x[0][2] = k2 * r.s2;
-        ex[0] = 0;
-        flag = 1;
-      } else {
-        double T[3][3];
-        trans_at(C, r.t, T);
-        fwd_step(x[0][0], x[0][1], x[0][2], T, r);
-        if (flag != 1) {
-          fwd_step(x[1][0], x[1][1], x[1][2], T, r);
-          fwd_step(x[2][0], x[2][1], x[2][2], T, r);
-          flag = 0;
-        }
-      }
-    }
-    if ((it & (kRescale / kUnroll - 1)) == 0) {
-      ex[0] += rescale3(x[0][0], x[0][1], x[0][2]);
-      if (flag == 0) {
-        ex[1] += rescale3(x[1][0], x[1][1], x[1][2]);
-        ex[2] += rescale3(x[2][0], x[2][1], x[2][2]);
-      }
-    }
-  }
-  ex[0] += rescale3(x[0][0], x[0][1], x[0][2]);
-  if (flag == 0) {
-    ex[1] += rescale3(x[1][0], x[1][1], x[1][2]);
-    ex[2] += rescale3(x[2][0], x[2][1], x[2][2]);
-  }
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-#pragma unroll
-    for (int y = 0; y < 3; y++) O.m[(size_t)(i * 3 + y) * n + tid] = x[i][y];
-    O.e[(size_t)i * n + tid] = ex[i];
-  }
-  O.flag[tid] = flag;
-}
-
-// alpha <- alpha * (chunk product); keeps alpha scaled, returns the exponent moved out
-__device__ inline int apply_chunk_fwd(double &f0, double &f1, double &f2, const ChunkOut &O, long n, long at) {
-  double a[3] = {f0, f1, f2};
-  int e[3] = {O.e[at], O.e[n + at], O.e[2 * n + at]};
-  int emax = -2147483647;
-  for (int i = 0; i < 3; i++)
-    if (a[i] > 0 && e[i] > emax) emax = e[i];
-  if (emax == -2147483647) { f0 = f1 = f2 = 0; return 0; }
-  double r0 = 0, r1 = 0, r2 = 0;
-  for (int i = 0; i < 3; i++) {
-    if (!(a[i] > 0)) continue;
-    double w = ldexp(a[i], e[i] - emax);
-    r0 += w * O.m[(size_t)(i * 3 + 0) * n + at];
-    r1 += w * O.m[(size_t)(i * 3 + 1) * n + at];
-    r2 += w * O.m[(size_t)(i * 3 + 2) * n + at];
-  }
-  f0 = r0; f1 = r1; f2 = r2;
-  return emax;
-}
-
-// K5 combine: folds the C chunk products of every lane into -log-likelihood.
-__global__ void __launch_bounds__(256)
-like_combine_kernel(ChunkOut O, const double *__restrict__ params, int nlanes, int nchunk, double alim1,
-                    double *__restrict__ out) {
-  int l = blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= nlanes) return;
-  double a, k2, k1, k0;
-  if (!lane_params(params, l, alim1, true, a, k2, k1, k0)) { out[l] = 10000000.0; return; }
-  long n = (long)nlanes * nchunk;
-  double f0 = 0, f1 = 0, f2 = 0;
-  long esum = 0;
-  bool started = false;
-  for (int c = 0; c < nchunk; c++) {
-    long at = (long)c * nlanes + l;
-    int flag = O.flag[at];
-    if (flag == 2) continue;
-    if (flag == 1) {
-      f0 = O.m[at]; f1 = O.m[n + at]; f2 = O.m[2 * n + at];
-      esum = O.e[at];
-      started = true;
-    } else if (started) {
-      esum += apply_chunk_fwd(f0, f1, f2, O, n, at);
-      esum += rescale3(f0, f1, f2);
-    }
-  }
-  double tot = f0 + f1 + f2;
-  out[l] = started ? -(log(tot) + (double)esum * kLn2) : nan("");
-}
-
-// K6.  Normalised forward vectors go to fwd[s * P + p] (24 B); the boundary vectors of the chunked sweep to
-// bnd: astart[(c * P + p) * 3 ..] = forward vector entering chunk c, bend[...] = backward vector at the last kept
-// SNP of chunk c.
-struct __attribute__((aligned(8))) Fwd3 {
-  double f0, f1, f2;
-};
-
-__device__ inline void norm_sum(double &x0, double &x1, double &x2) {
-  double inv = 1.0 / (x0 + x1 + x2);
-  x0 *= inv; x1 *= inv; x2 *= inv;
-}
-__device__ inline void norm_max(double &x0, double &x1, double &x2) {
-  double inv = 1.0 / fmax(x0, fmax(x1, x2));
-  x0 *= inv; x1 *= inv; x2 *= inv;
-}
-
-__global__ void __launch_bounds__(256)
-decode_combine_kernel(ChunkOut O, int P, int nchunk, double *__restrict__ astart, double *__restrict__ bend) {
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  long n = (long)P * nchunk;
-  double f0 = 0, f1 = 0, f2 = 0;
-  bool started = false;
-  for (int c = 0; c < nchunk; c++) {
-    long at = (long)c * P + p;
-    astart[at * 3] = f0; astart[at * 3 + 1] = f1; astart[at * 3 + 2] = f2;
-    int flag = O.flag[at];
-    if (flag == 2) continue;
-    if (flag == 1) {
-      f0 = O.m[at]; f1 = O.m[n + at]; f2 = O.m[2 * n + at];
-      started = true;
-    } else if (started) {
-      apply_chunk_fwd(f0, f1, f2, O, n, at);
-    }
-    if (started) norm_sum(f0, f1, f2);
-  }
-  double b0 = 1, b1 = 1, b2 = 1;
-  for (int c = nchunk - 1; c >= 0; c--) {
-    long at = (long)c * P + p;
-    bend[at * 3] = b0; bend[at * 3 + 1] = b1; bend[at * 3 + 2] = b2;
-    if (O.flag[at] != 0) continue;
-    // beta_start[i] = 2^{e[i]} sum_y X[i][y] beta[y]
-    double v[3];
-    int e[3], emax = -2147483647;
-    for (int i = 0; i < 3; i++) {
-      v[i] = O.m[(size_t)(i * 3 + 0) * n + at] * b0 + O.m[(size_t)(i * 3 + 1) * n + at] * b1 +
-             O.m[(size_t)(i * 3 + 2) * n + at] * b2;
-      e[i] = O.e[(size_t)i * n + at];
-      if (v[i] > 0 && e[i] > emax) emax = e[i];
-    }
-    if (emax == -2147483647) continue;
-    b0 = v[0] > 0 ? ldexp(v[0], e[0] - emax) : 0;
-    b1 = v[1] > 0 ? ldexp(v[1], e[1] - emax) : 0;
-    b2 = v[2] > 0 ? ldexp(v[2], e[2] - emax) : 0;
-    norm_max(b0, b1, b2);
-  }
-}
-
-// forward sweep inside one chunk; thread = (chunk c, pair p); astart == nullptr means nchunk == 1
-__global__ void __launch_bounds__(256)
-decode_fwd_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *__restrict__ params,
-                  int double_recom, int nchunk, int chunk_len, const double *__restrict__ astart,
-                  Fwd3 *__restrict__ fwd, int *__restrict__ nsnp) {
-  long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= (long)P * nchunk) return;
-  int p = (int)(tid % P), c = (int)(tid / P);
-  double a, k2, k1, k0;
-  lane_params(params, p, 0, false, a, k2, k1, k0);
-  k0 = 1 - k2 - k1;  // decodek2, :1018
-  Trans C = make_trans(a, k2, k1, k0, double_recom);
-  int sb = c * chunk_len, se = min(M, sb + chunk_len);
-  double f0 = 0, f1 = 0, f2 = 0;
-  if (astart) { f0 = astart[tid * 3]; f1 = astart[tid * 3 + 1]; f2 = astart[tid * 3 + 2]; }
-  const EmisRec *col = rec + p;
-  int m = 0;
-  EmisRec nx[kUnroll];
-#pragma unroll
-  for (int u = 0; u < kUnroll; u++)
-    if (sb + u < se) nx[u] = col[(size_t)(sb + u) * P];
-  for (int s0 = sb; s0 < se; s0 += kUnroll) {
-    EmisRec cur[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; u++) cur[u] = nx[u];
-#pragma unroll
-    for (int u = 0; u < kUnroll; u++)
-      if (s0 + kUnroll + u < se) nx[u] = col[(size_t)(s0 + kUnroll + u) * P];
-#pragma unroll
-    for (int u = 0; u < kUnroll; u++) {
-      if (s0 + u >= se) break;
-      const EmisRec &r = cur[u];
-      if (r.t == kDropped) continue;
-      m++;
-      if (r.t == kFirst) {
-        f0 = k0 * r.s0; f1 = k1 * r.s1; f2 = k2 * r.s2;
-      } else {
-        double T[3][3];
-        trans_at(C, r.t, T);
-        fwd_step(f0, f1, f2, T, r);
-      }
-      norm_sum(f0, f1, f2);
-      Fwd3 o = {f0, f1, f2};
-      fwd[(size_t)(s0 + u) * P + p] = o;
-    }
-  }
-  if (nsnp) atomicAdd(&nsnp[p], m);
-}
-
-// backward sweep inside one chunk + posterior.  post is P x 3 x M (pair-major, as the host writer wants it):
-// row0 IBD2, row1 IBD1, row2 IBD0 (decodek2, :1133-1137); -1 where the SNP is dropped (.post writer, :126-133).
-// posterior_x(s) = fwd_x(s) bwd_x(s) / sum_y fwd_y(s) bwd_y(s): every scale factor cancels.
-__global__ void __launch_bounds__(256)
-decode_bwd_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *__restrict__ params,
-                  int double_recom, int nchunk, int chunk_len, const double *__restrict__ bend,
-                  const Fwd3 *__restrict__ fwd, double *__restrict__ post) {
-  long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= (long)P * nchunk) return;
-  int p = (int)(tid % P), c = (int)(tid / P);
-  double a, k2, k1, k0;
-  lane_params(params, p, 0, false, a, k2, k1, k0);
-  k0 = 1 - k2 - k1;
-  Trans C = make_trans(a, k2, k1, k0, double_recom);
-  int sb = c * chunk_len, se = min(M, sb + chunk_len);
-  double *o2 = post + (size_t)p * 3 * M, *o1 = o2 + M, *o0 = o1 + M;
-  double b0 = 1, b1 = 1, b2 = 1;
-  if (bend) { b0 = bend[tid * 3]; b1 = bend[tid * 3 + 1]; b2 = bend[tid * 3 + 2]; }
-  const EmisRec *col = rec + p;
-  // emission and distance of the next kept SNP (the one the backward vector currently refers to)
-  double nt = 0, ns0 = 0, ns1 = 0, ns2 = 0;
-  bool have_next = false;
-  EmisRec nx[kUnroll];
-#pragma unroll
-  for (int u = 0; u < kUnroll; u++)
-    if (se - 1 - u >= sb) nx[u] = col[(size_t)(se - 1 - u) * P];
-  for (int s0 = se - 1; s0 >= sb; s0 -= kUnroll) {
-    EmisRec cur[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; u++) cur[u] = nx[u];
-#pragma unroll
-    for (int u = 0; u < kUnroll; u++)
-      if (s0 - kUnroll - u >= sb) nx[u] = col[(size_t)(s0 - kUnroll - u) * P];
-#pragma unroll
-    for (int u = 0; u < kUnroll; u++) {
-      int s = s0 - u;
-      if (s < sb) break;
-      const EmisRec &r = cur[u];
-      if (r.t == kDropped) {
-        o0[s] = -1; o1[s] = -1; o2[s] = -1;
-        continue;
-      }
-      if (have_next) {  // beta_x(s) = sum_y T_xy(next) S_y(next) beta_y(next), :1116-1125
-        double T[3][3];
-        trans_at(C, nt, T);
-        double q0 = ns0 * b0, q1 = ns1 * b1, q2 = ns2 * b2;
-        double n0 = q2 * T[0][2] + q1 * T[0][1] + q0 * T[0][0];
-        double n1 = q2 * T[1][2] + q1 * T[1][1] + q0 * T[1][0];
-        double n2 = q2 * T[2][2] + q1 * T[2][1] + q0 * T[2][0];
-        b0 = n0; b1 = n1; b2 = n2;
-        norm_max(b0, b1, b2);
-      }
-      Fwd3 f = fwd[(size_t)s * P + p];
-      double p0 = f.f0 * b0, p1 = f.f1 * b1, p2 = f.f2 * b2;
-      double inv = 1.0 / (p0 + p1 + p2);
-      o0[s] = p0 * inv; o1[s] = p1 * inv; o2[s] = p2 * inv;
-      nt = r.t; ns0 = r.s0; ns1 = r.s1; ns2 = r.s2;
-      have_next = true;
-    }
-  }
-}
-
-// K7 Viterbi (:1289-1420), log domain as the reference (max3 / which_max tie rules kept, and the start quirk:
-// every state starts from max(log k) + its emission, :1356-1359).  bp: M x P bytes (3 x 2-bit back pointers).
-__device__ inline double vmax3(double a, double b, double c) {
-  if (a > b && a > c) return a;
-  else if (b > a && b > c) return b;
-  return c;
-}
-__device__ inline int vwhich3(double a, double b, double c) {
-  if (a > b && a > c) return 0;
-  else if (b > a && b > c) return 1;
-  return 2;
-}
-
 __global__ void __launch_bounds__(256)
 viterbi_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *__restrict__ params, int double_recom,
                uint8_t *__restrict__ bp, int8_t *__restrict__ path) {
@@ -476,21 +610,21 @@ viterbi_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *__re
   if (p >= P) return;
   double a = params[3 * p], k2 = params[3 * p + 1], k1 = params[3 * p + 2];
   double k0 = 1 - k2 - k1;
-  Trans C = make_trans(a, k2, k1, k0, double_recom);
+  RefTrans C = make_ref_trans(a, k2, k1, k0, double_recom);
   double v0 = 0, v1 = 0, v2 = 0;
   bool started = false;
   for (int s = 0; s < M; s++) {
     EmisRec r = rec[(size_t)s * P + p];
-    if (r.t == kDropped) continue;
+    if (rec_dropped(r)) continue;
     double l0 = log(r.s0), l1 = log(r.s1), l2 = log(r.s2);
-    if (r.t == kFirst) {
+    if (!started) {
       double mx = fmax(log(k0), fmax(log(k1), log(k2)));
       v0 = mx + l0; v1 = mx + l1; v2 = mx + l2;
       started = true;
       bp[(size_t)s * P + p] = 0;
     } else {
       double T[3][3];
-      trans_at(C, r.t, T);
+      ref_trans_at(C, r.t, T);
       double L[3][3];
       for (int x = 0; x < 3; x++)
         for (int y = 0; y < 3; y++) L[x][y] = log(T[x][y]);
@@ -507,7 +641,7 @@ viterbi_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *__re
   int8_t *out = path + (size_t)p * M;
   int cur = started ? vwhich3(v0, v1, v2) : -1;
   for (int s = M - 1; s >= 0; s--) {
-    if (rec[(size_t)s * P + p].t == kDropped) { out[s] = -1; continue; }
+    if (rec_dropped(rec[(size_t)s * P + p])) { out[s] = -1; continue; }
     out[s] = (int8_t)cur;
     cur = (bp[(size_t)s * P + p] >> (2 * cur)) & 3;
   }

@@ -73,12 +73,12 @@ struct relate_hip_ctx {
   // device: work
   DBuf<int32_t> dLanePair;
   DBuf<double> dParams, dOut, dPost;
-  DBuf<Fwd3> dFwd;
+  DBuf<double> dFwd;  // 3 planes x M x P normalised forward vectors
   DBuf<uint8_t> dBp;
   DBuf<int8_t> dPath;
   DBuf<int> dNsnp;
   DBuf<double> dCm, dAstart, dBend;  // chunk products and boundary vectors of the chunked sweeps
-  DBuf<int> dCe, dCflag;
+  DBuf<int> dCe;
   double timings[4] = {0, 0, 0, 0};
 };
 
@@ -147,10 +147,17 @@ int stage_block(relate_hip_t h, const int32_t *pairs, int P) {
   return 0;
 }
 
-// SNP-axis chunking: enough threads to fill 256 CUs (about 6 waves per SIMD), chunks of at least 256 SNPs
+// SNP-axis chunking.  A sweep lane carries a serial chain of M steps; below about two waves per SIMD the
+// machine idles, so the SNP axis is cut until there are enough threads -- but a chunked step costs ~1.5x a plain
+// one, so a launch that already has >= ~1.5 waves per SIMD stays a single sweep.  Chunks are multiples of 8 SNPs
+// (the posterior tiles of decode_bwd_kernel) and at least 256 SNPs long.
 void pick_chunks(int M, long lanes, int *nchunk, int *chunk_len) {
-  const long target = 256L * 4 * 64 * 6;
-  long c = lanes > 0 ? (target + lanes - 1) / lanes : 1;
+  const long simd_lanes = 256L * 4 * 64;  // one wave on every SIMD
+  long c = 1;
+  if (lanes < simd_lanes * 3 / 2) {
+    const long target = simd_lanes * 4;
+    c = lanes > 0 ? (target + lanes - 1) / lanes : 1;
+  }
   long cmax = std::max(1, M / 256);
   if (c > cmax) c = cmax;
   if (c < 1) c = 1;
@@ -160,13 +167,13 @@ void pick_chunks(int M, long lanes, int *nchunk, int *chunk_len) {
   *nchunk = (M + len - 1) / len;
 }
 
-int ensure_chunk_buffers(relate_hip_t h, long n, ChunkOut *O) {
+inline int pad256(int n) { return (n + 255) / 256 * 256; }
+
+int ensure_chunk_buffers(relate_hip_t h, size_t n, ChunkOut *O) {
   HIPCHK(h, h->dCm.ensure((size_t)9 * n));
   HIPCHK(h, h->dCe.ensure((size_t)3 * n));
-  HIPCHK(h, h->dCflag.ensure((size_t)n));
   O->m = h->dCm.p;
   O->e = h->dCe.p;
-  O->flag = h->dCflag.p;
   return 0;
 }
 
@@ -174,20 +181,31 @@ int ensure_chunk_buffers(relate_hip_t h, long n, ChunkOut *O) {
 int launch_like(relate_hip_t h, int P, int nl) {
   int nchunk, clen;
   pick_chunks(h->M, nl, &nchunk, &clen);
+  const bool dr = h->o.double_recom != 0;
   if (nchunk == 1) {
-    hipLaunchKernelGGL(like_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, h->dRec.p, h->M, P,
-                       h->dLanePair.p, h->dParams.p, nl, h->o.alim[1], h->o.double_recom, h->dOut.p);
+    if (dr)
+      hipLaunchKernelGGL(like_kernel<true>, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, h->dRec.p, h->M, P,
+                         h->dLanePair.p, h->dParams.p, nl, h->o.alim[1], h->dOut.p);
+    else
+      hipLaunchKernelGGL(like_kernel<false>, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, h->dRec.p, h->M, P,
+                         h->dLanePair.p, h->dParams.p, nl, h->o.alim[1], h->dOut.p);
     HIPCHK(h, hipGetLastError());
     return 0;
   }
-  long n = (long)nl * nchunk;
+  int nlp = pad256(nl);
+  size_t n = (size_t)nlp * nchunk;
   ChunkOut O;
   int rc = ensure_chunk_buffers(h, n, &O);
   if (rc) return rc;
-  hipLaunchKernelGGL(chunk_matrix_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, h->stream, h->dRec.p, h->M, P,
-                     h->dLanePair.p, h->dParams.p, nl, nchunk, clen, h->o.alim[1], h->o.double_recom, 1, O);
+  dim3 grid((unsigned)((size_t)(nlp / 256) * nchunk));
+  if (dr)
+    hipLaunchKernelGGL(chunk_matrix_kernel<true>, grid, dim3(256), 0, h->stream, h->dRec.p, h->M, P, h->dLanePair.p,
+                       h->dParams.p, nl, nlp, nchunk, clen, h->o.alim[1], 1, O);
+  else
+    hipLaunchKernelGGL(chunk_matrix_kernel<false>, grid, dim3(256), 0, h->stream, h->dRec.p, h->M, P, h->dLanePair.p,
+                       h->dParams.p, nl, nlp, nchunk, clen, h->o.alim[1], 1, O);
   HIPCHK(h, hipGetLastError());
-  hipLaunchKernelGGL(like_combine_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, O, h->dParams.p, nl,
+  hipLaunchKernelGGL(like_combine_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, O, h->dParams.p, nl, nlp,
                      nchunk, h->o.alim[1], h->dOut.p);
   HIPCHK(h, hipGetLastError());
   return 0;
@@ -393,31 +411,46 @@ int launch_decode(relate_hip_t h, int P) {
   const int M = h->M;
   int nchunk, clen;
   pick_chunks(M, P, &nchunk, &clen);
-  long n = (long)P * nchunk;
+  const bool dr = h->o.double_recom != 0;
+  const int nlp = pad256(P);
   const double *astart = nullptr, *bend = nullptr;
   HIPCHK(h, hipMemsetAsync(h->dNsnp.p, 0, sizeof(int) * P, h->stream));
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  dim3 grid((unsigned)((size_t)(nlp / 256) * nchunk));
   if (nchunk > 1) {
+    size_t n = (size_t)nlp * nchunk;
     ChunkOut O;
     int rc = ensure_chunk_buffers(h, n, &O);
     if (rc) return rc;
     HIPCHK(h, h->dAstart.ensure((size_t)3 * n));
     HIPCHK(h, h->dBend.ensure((size_t)3 * n));
-    hipLaunchKernelGGL(chunk_matrix_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, h->stream, h->dRec.p, M, P,
-                       (const int32_t *)nullptr, h->dParams.p, P, nchunk, clen, h->o.alim[1], h->o.double_recom, 0, O);
+    if (dr)
+      hipLaunchKernelGGL(chunk_matrix_kernel<true>, grid, dim3(256), 0, h->stream, h->dRec.p, M, P,
+                         (const int32_t *)nullptr, h->dParams.p, P, nlp, nchunk, clen, h->o.alim[1], 0, O);
+    else
+      hipLaunchKernelGGL(chunk_matrix_kernel<false>, grid, dim3(256), 0, h->stream, h->dRec.p, M, P,
+                         (const int32_t *)nullptr, h->dParams.p, P, nlp, nchunk, clen, h->o.alim[1], 0, O);
     HIPCHK(h, hipGetLastError());
-    hipLaunchKernelGGL(decode_combine_kernel, dim3(blocks_for(P, 256)), dim3(256), 0, h->stream, O, P, nchunk,
-                       h->dAstart.p, h->dBend.p);
+    hipLaunchKernelGGL(decode_combine_kernel, dim3(blocks_for(P, 256)), dim3(256), 0, h->stream, O, h->dParams.p, P,
+                       nlp, nchunk, h->dAstart.p, h->dBend.p);
     HIPCHK(h, hipGetLastError());
     astart = h->dAstart.p;
     bend = h->dBend.p;
   }
-  hipLaunchKernelGGL(decode_fwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, h->stream, h->dRec.p, M, P,
-                     h->dParams.p, h->o.double_recom, nchunk, clen, astart, h->dFwd.p, h->dNsnp.p);
+  if (dr)
+    hipLaunchKernelGGL(decode_fwd_kernel<true>, grid, dim3(256), 0, h->stream, h->dRec.p, M, P, h->dParams.p, nlp, clen,
+                       astart, h->dFwd.p, h->dNsnp.p);
+  else
+    hipLaunchKernelGGL(decode_fwd_kernel<false>, grid, dim3(256), 0, h->stream, h->dRec.p, M, P, h->dParams.p, nlp,
+                       clen, astart, h->dFwd.p, h->dNsnp.p);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-  hipLaunchKernelGGL(decode_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, h->stream, h->dRec.p, M, P,
-                     h->dParams.p, h->o.double_recom, nchunk, clen, bend, h->dFwd.p, h->dPost.p);
+  if (dr)
+    hipLaunchKernelGGL(decode_bwd_kernel<true>, grid, dim3(256), 0, h->stream, h->dRec.p, M, P, h->dParams.p, nlp, clen,
+                       bend, h->dFwd.p, h->dPost.p);
+  else
+    hipLaunchKernelGGL(decode_bwd_kernel<false>, grid, dim3(256), 0, h->stream, h->dRec.p, M, P, h->dParams.p, nlp,
+                       clen, bend, h->dFwd.p, h->dPost.p);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
   return 0;
@@ -431,7 +464,7 @@ int decode_block(relate_hip_t h, int P, const double *params, double *post, int8
   HIPCHK(h, hipMemcpyAsync(h->dParams.p, params, sizeof(double) * 3 * P, hipMemcpyHostToDevice, h->stream));
   bool ran = false;
   if (post || nsnp_out || !copy_back) {
-    HIPCHK(h, h->dFwd.ensure((size_t)M * P));
+    HIPCHK(h, h->dFwd.ensure((size_t)3 * M * P));
     HIPCHK(h, h->dPost.ensure((size_t)3 * M * P));
     int rc = launch_decode(h, P);
     if (rc) return rc;
@@ -495,7 +528,7 @@ int relate_hip_destroy(relate_hip_t h) {
   h->dPBa.release(); h->dPba.release(); h->dTab1.release(); h->dTabL.release(); h->dChoose.release();
   h->dRec.release(); h->dPairs.release(); h->dLanePair.release(); h->dParams.release(); h->dOut.release();
   h->dPost.release(); h->dFwd.release(); h->dBp.release(); h->dPath.release(); h->dNsnp.release();
-  h->dCm.release(); h->dAstart.release(); h->dBend.release(); h->dCe.release(); h->dCflag.release();
+  h->dCm.release(); h->dAstart.release(); h->dBend.release(); h->dCe.release();
   for (int i = 0; i < 4; i++)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -739,9 +772,9 @@ int relate_hip_pair_emissions(relate_hip_t h, int ind1, int ind2, int *keep, dou
   std::vector<EmisRec> r(h->M);
   HIPCHK(h, hipMemcpy(r.data(), h->dRec.p, sizeof(EmisRec) * h->M, hipMemcpyDeviceToHost));
   for (int s = 0; s < h->M; s++) {
-    bool k = r[s].t != -1.0;
+    bool k = !std::signbit(r[s].t);  // dropped SNPs carry t = -0.0
     if (keep) keep[s] = k ? 1 : 0;
-    if (t) t[s] = r[s].t == -2.0 ? 0.0 : r[s].t;
+    if (t) t[s] = k ? r[s].t : -1.0;
     if (S) {
       S[s] = k ? r[s].s0 : 0;
       S[(size_t)h->M + s] = k ? r[s].s1 : 0;
@@ -795,7 +828,7 @@ int relate_hip_decode(relate_hip_t h, const int32_t *pairs, int P, const double 
   if (rc) return rc;
   if (!pairs || !params || P < 0) return fail(h, RELATE_E_ARG, "bad arguments");
   h->timings[2] = h->timings[3] = 0;
-  size_t lim = pair_block_limit(h, sizeof(EmisRec) + sizeof(Fwd3) + 3 * sizeof(double) + 2);
+  size_t lim = pair_block_limit(h, sizeof(EmisRec) + 6 * sizeof(double) + 2);
   for (long b0 = 0; b0 < P; b0 += (long)lim) {
     int pb = (int)std::min<long>((long)lim, P - b0);
     rc = stage_block(h, pairs + 2 * b0, pb);
@@ -813,7 +846,7 @@ int relate_hip_run_pairs(relate_hip_t h, const int32_t *pairs, int P, const doub
   if (rc) return rc;
   if (!pairs || !out || P < 0) return fail(h, RELATE_E_ARG, "bad arguments");
   h->timings[1] = h->timings[2] = h->timings[3] = 0;
-  size_t lim = pair_block_limit(h, sizeof(EmisRec) + sizeof(Fwd3) + 3 * sizeof(double) + 2);
+  size_t lim = pair_block_limit(h, sizeof(EmisRec) + 6 * sizeof(double) + 2);
   std::vector<double> par;
   std::vector<int> ns;
   for (long b0 = 0; b0 < P; b0 += (long)lim) {
