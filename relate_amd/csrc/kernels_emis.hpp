@@ -262,4 +262,144 @@ __global__ void stage_pairs_kernel(const uint64_t *__restrict__ G, int M, int W,
   }
 }
 
+// ---- windowed staging (back2 <= 32) ---------------------------------------------------------------------------
+// Individual-major copy of the packed genotypes: Gt[ind * Wt + w] holds SNPs 32w .. 32w+31 of one individual at
+// 2 bits each, so a lane (= one pair) fetches 32 SNPs of both individuals with two 8-byte loads and does the rest
+// of the per-SNP work (missingness, window search, genotype codes) on registers.
+__global__ void transpose_geno_kernel(const uint64_t *__restrict__ G, int N, int M, int W, int Wt,
+                                      uint64_t *__restrict__ Gt) {
+  long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (long)N * Wt) return;
+  int ind = (int)(tid % N), w = (int)(tid / N);  // lanes walk individuals: neighbouring bits of the same words
+  uint64_t out = 0;
+  int s0 = w * 32;
+  for (int k = 0; k < 32; k++) {
+    int s = s0 + k;
+    if (s >= M) break;
+    uint64_t g = (G[(size_t)s * W + (ind >> 5)] >> (2 * (ind & 31))) & 3u;
+    out |= g << (2 * k);
+  }
+  Gt[(size_t)ind * Wt + w] = out;
+}
+
+// tabD[s][dd][code][3]: emission of SNP s conditional on SNP s-1-dd for every depth dd < back2 (the per-pair
+// re-indexing of remove_cross can select any of them); zero where the earlier SNP does not exist.
+__global__ void table_ld_depth_kernel(const double *__restrict__ pBA, const double *__restrict__ pbA,
+                                      const double *__restrict__ pBa, const double *__restrict__ pba, int M, int back2,
+                                      double eps, double *__restrict__ tabD) {
+  long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (long)M * back2 * 81) return;
+  int code = (int)(tid % 81);
+  long sd = tid / 81;
+  int dd = (int)(sd % back2), s = (int)(sd / back2);
+  double S[3] = {0, 0, 0};
+  if (s - 1 - dd >= 0) {
+    size_t at = (size_t)dd * M + s;
+    int o2p = code % 3, o1p = (code / 3) % 3, o2c = (code / 9) % 3, o1c = code / 27;
+    emis_cond(pBA[at], pbA[at], pBa[at], pba[at], o1c + 1, o2c + 1, o1p + 1, o2p + 1, eps, S);
+  }
+  double *o = tabD + (size_t)tid * 3;
+  o[0] = S[0]; o[1] = S[1]; o[2] = S[2];
+}
+
+__device__ inline uint64_t both_present(uint64_t a, uint64_t b) {  // bit 2k set iff SNP k is non-missing in both
+  return (a | (a >> 1)) & (b | (b >> 1)) & 0x5555555555555555ull;
+}
+__device__ inline uint32_t win2(uint64_t lo, uint64_t hi, int q) {  // 2-bit field q of the 64-field window {lo, hi}
+  uint64_t w = q < 32 ? lo : hi;
+  return (uint32_t)(w >> (2 * (q & 31))) & 3u;
+}
+
+// K4 for back2 <= 32.  Workgroup = 256 consecutive pairs x one run of `words` 32-SNP words, so the SNP index is
+// scalar and pos / mea are scalar loads.  Every lane applies the clean form of remove_cross + getHighestId
+// (SURVEY 8a): walk the previous SNPs dd = 0..back2-1, take the first `back` that are kept for the pair, choose
+// the first strictly largest LD measure; a zero-filled row beyond the window wins over negative measures.  For a
+// pair with no missing genotype in the window this is exactly the global choose.  The emission is then a lookup in
+// tabD; no lane evaluates the 81-term polynomial.
+__global__ void __launch_bounds__(256)
+stage_pairs_win_kernel(const uint64_t *__restrict__ Gt, int M, int Wt, const int32_t *__restrict__ pairs, int P,
+                       int words, const double *__restrict__ pos, const double *__restrict__ tab1,
+                       const double *__restrict__ tabD, const double *__restrict__ mea, int useLD, int back,
+                       int back2, EmisRec *__restrict__ rec) {
+  int bpc = (P + 255) / 256;
+  int c = blockIdx.x / bpc;
+  int p = (blockIdx.x % bpc) * 256 + threadIdx.x;
+  if (p >= P) return;
+  const uint64_t *r1 = Gt + (size_t)pairs[2 * p] * Wt, *r2 = Gt + (size_t)pairs[2 * p + 1] * Wt;
+  int w0 = c * words, w1 = min(Wt, w0 + words);
+  uint64_t a_lo = 0, b_lo = 0;  // previous word of the two individuals
+  int last = -1;                // last kept SNP before the current one
+  if (w0 > 0) {
+    a_lo = r1[w0 - 1];
+    b_lo = r2[w0 - 1];
+    uint64_t K = both_present(a_lo, b_lo);
+    if (K) {
+      last = (w0 - 1) * 32 + (63 - __clzll(K)) / 2;
+    } else {
+      for (int w = w0 - 2; w >= 0; w--) {  // a run of >= 32 missing SNPs: rare
+        uint64_t K2 = both_present(r1[w], r2[w]);
+        if (K2) { last = w * 32 + (63 - __clzll(K2)) / 2; break; }
+      }
+    }
+  }
+  for (int w = w0; w < w1; w++) {
+    uint64_t a_hi = r1[w], b_hi = r2[w];
+    uint64_t K_lo = both_present(a_lo, b_lo), K_hi = both_present(a_hi, b_hi);
+    int kmax = min(32, M - w * 32);
+    for (int k = 0; k < kmax; k++) {
+      int s = w * 32 + k, q = 32 + k;
+      uint32_t g1 = (uint32_t)(a_hi >> (2 * k)) & 3u, g2 = (uint32_t)(b_hi >> (2 * k)) & 3u;
+      EmisRec r;
+      if (g1 == 0 || g2 == 0) {
+        r.t = -0.0; r.s0 = 1; r.s1 = 1; r.s2 = 1;
+      } else {
+        const double *e;
+        bool zero = false;
+        if (last < 0) {
+          r.t = 0.0;
+          e = tab1 + ((size_t)s * 9 + (g1 - 1) * 3 + (g2 - 1)) * 3;
+        } else {
+          double d = pos[s] - pos[last];
+          r.t = d < 0 ? 10000000.0 : d;
+          if (!useLD) {
+            e = tab1 + ((size_t)s * 9 + (g1 - 1) * 3 + (g2 - 1)) * 3;
+          } else {
+            int nfound = 0, bestdd = -1;
+            double bv = 0;
+            int ddmax = min(back2, s);
+            for (int dd = 0; dd < ddmax; dd++) {
+              if (__all(nfound >= back)) break;
+              int q2 = q - 1 - dd;
+              bool kept = ((q2 < 32 ? K_lo : K_hi) >> (2 * (q2 & 31))) & 1u;
+              bool take = kept && nfound < back;
+              double v = mea[(size_t)dd * (M - 1) + (s - 1)];
+              bool better = take && (nfound == 0 || v > bv);
+              bv = better ? v : bv;
+              bestdd = better ? dd : bestdd;
+              nfound += take ? 1 : 0;
+            }
+            if (nfound < back && 0.0 > bv) bestdd = -1;  // a zero-filled row wins getHighestId (:492)
+            if (bestdd < 0) {
+              zero = true;
+              e = tab1;
+            } else {
+              int q2 = q - 1 - bestdd;
+              uint32_t h1 = win2(a_lo, a_hi, q2), h2 = win2(b_lo, b_hi, q2);
+              int code = (((g1 - 1) * 3 + (g2 - 1)) * 3 + (h1 - 1)) * 3 + (h2 - 1);
+              e = tabD + (((size_t)s * back2 + bestdd) * 81 + code) * 3;
+            }
+          }
+        }
+        r.s0 = zero ? 0.0 : e[0];
+        r.s1 = zero ? 0.0 : e[1];
+        r.s2 = zero ? 0.0 : e[2];
+        last = s;
+      }
+      rec[(size_t)s * P + p] = r;
+    }
+    a_lo = a_hi;
+    b_lo = b_hi;
+  }
+}
+
 }  // namespace relate

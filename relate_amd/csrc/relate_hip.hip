@@ -63,8 +63,10 @@ struct relate_hip_ctx {
   std::vector<int> keep;  // Mraw: pre_calc_used_list
   std::vector<double> h_pos, h_maf;
   // device: data set
-  DBuf<uint64_t> dG;
-  DBuf<double> dPos, dMaf, dMea, dPBA, dPbA, dPBa, dPba, dTab1, dTabL;
+  DBuf<uint64_t> dG, dGt;  // SNP-major / individual-major 2-bit genotypes
+  int Wt = 0;
+  bool winMode = false;      // stage_pairs_win_kernel + depth table (back2 <= 32)
+  DBuf<double> dPos, dMaf, dMea, dPBA, dPbA, dPBa, dPba, dTab1, dTabL, dTabD;
   DBuf<int> dChoose;
   // device: staged pair block
   DBuf<EmisRec> dRec;
@@ -131,12 +133,21 @@ int stage_block(relate_hip_t h, const int32_t *pairs, int P) {
   HIPCHK(h, h->dRec.ensure((size_t)h->M * P));
   HIPCHK(h, h->dPairs.ensure((size_t)2 * P));
   HIPCHK(h, hipMemcpyAsync(h->dPairs.p, pairs, sizeof(int32_t) * 2 * P, hipMemcpyHostToDevice, h->stream));
-  const int chunk = 64;
-  long nthreads = (long)P * ((h->M + chunk - 1) / chunk);
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-  hipLaunchKernelGGL(stage_pairs_kernel, dim3(blocks_for(nthreads, 256)), dim3(256), 0, h->stream, h->dG.p, h->M, h->W,
-                     h->dPairs.p, P, chunk, h->dPos.p, h->dTab1.p, h->dTabL.p, h->dChoose.p, h->dMea.p, h->dPBA.p,
-                     h->dPbA.p, h->dPBa.p, h->dPba.p, h->useLD, h->o.back, h->back2, h->o.epsilon, h->dRec.p);
+  if (h->winMode) {
+    const int words = 2;  // 64 SNPs per thread
+    unsigned grid = (unsigned)(((size_t)(h->Wt + words - 1) / words) * ((P + 255) / 256));
+    hipLaunchKernelGGL(stage_pairs_win_kernel, dim3(grid), dim3(256), 0, h->stream, h->dGt.p, h->M, h->Wt, h->dPairs.p,
+                       P, words, h->dPos.p, h->dTab1.p, h->dTabD.p, h->dMea.p, h->useLD, h->o.back, h->back2,
+                       h->dRec.p);
+  } else {
+    const int chunk = 64;
+    long nthreads = (long)P * ((h->M + chunk - 1) / chunk);
+    hipLaunchKernelGGL(stage_pairs_kernel, dim3(blocks_for(nthreads, 256)), dim3(256), 0, h->stream, h->dG.p, h->M,
+                       h->W, h->dPairs.p, P, chunk, h->dPos.p, h->dTab1.p, h->dTabL.p, h->dChoose.p, h->dMea.p,
+                       h->dPBA.p, h->dPbA.p, h->dPBa.p, h->dPba.p, h->useLD, h->o.back, h->back2, h->o.epsilon,
+                       h->dRec.p);
+  }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -526,6 +537,7 @@ int relate_hip_destroy(relate_hip_t h) {
   (void)hipSetDevice(h->dev);
   h->dG.release(); h->dPos.release(); h->dMaf.release(); h->dMea.release(); h->dPBA.release(); h->dPbA.release();
   h->dPBa.release(); h->dPba.release(); h->dTab1.release(); h->dTabL.release(); h->dChoose.release();
+  h->dGt.release(); h->dTabD.release();
   h->dRec.release(); h->dPairs.release(); h->dLanePair.release(); h->dParams.release(); h->dOut.release();
   h->dPost.release(); h->dFwd.release(); h->dBp.release(); h->dPath.release(); h->dNsnp.release();
   h->dCm.release(); h->dAstart.release(); h->dBend.release(); h->dCe.release();
@@ -714,10 +726,36 @@ int relate_hip_precalc(relate_hip_t h, int *keep_out, int *M_out) {
     hipLaunchKernelGGL(choose_global_kernel, dim3(blocks_for(M, 256)), dim3(256), 0, st, h->dMea.p, M, o.back,
                        h->dChoose.p);
     PCHK(hipGetLastError());
-    PCHK(h->dTabL.ensure((size_t)M * 243));
-    hipLaunchKernelGGL(table_ld_kernel, dim3(blocks_for((long)M * 81, 256)), dim3(256), 0, st, h->dChoose.p,
-                       h->dPBA.p, h->dPbA.p, h->dPBa.p, h->dPba.p, M, o.epsilon, h->dTabL.p);
+  }
+  // staging mode: the windowed kernel needs back2 <= 32 and room for the depth table (M x back2 x 1944 B)
+  {
+    size_t freeb = 0, total = 0;
+    if (hipMemGetInfo(&freeb, &total) != hipSuccess) freeb = 0;
+    size_t need = h->useLD ? (size_t)M * h->back2 * 243 * sizeof(double) : 0;
+    h->winMode = h->back2 <= 32 && need <= freeb / 4;
+  }
+  if (h->winMode) {
+    h->Wt = (M + 31) / 32;
+    PCHK(h->dGt.ensure((size_t)N * h->Wt));
+    hipLaunchKernelGGL(transpose_geno_kernel, dim3(blocks_for((long)N * h->Wt, 256)), dim3(256), 0, st, Gfinal, N, M, W,
+                       h->Wt, h->dGt.p);
     PCHK(hipGetLastError());
+    if (h->useLD) {
+      PCHK(h->dTabD.ensure((size_t)M * h->back2 * 243));
+      hipLaunchKernelGGL(table_ld_depth_kernel, dim3(blocks_for((long)M * h->back2 * 81, 256)), dim3(256), 0, st,
+                         h->dPBA.p, h->dPbA.p, h->dPBa.p, h->dPba.p, M, h->back2, o.epsilon, h->dTabD.p);
+      PCHK(hipGetLastError());
+    }
+    h->dTabL.release();
+  } else {
+    h->dGt.release();
+    h->dTabD.release();
+    if (h->useLD) {
+      PCHK(h->dTabL.ensure((size_t)M * 243));
+      hipLaunchKernelGGL(table_ld_kernel, dim3(blocks_for((long)M * 81, 256)), dim3(256), 0, st, h->dChoose.p,
+                         h->dPBA.p, h->dPbA.p, h->dPBa.p, h->dPba.p, M, o.epsilon, h->dTabL.p);
+      PCHK(hipGetLastError());
+    }
   }
   PCHK(hipStreamSynchronize(st));
   cleanup();
