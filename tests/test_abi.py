@@ -66,3 +66,21 @@ def test_product_does_not_reference_the_oracle():
                 if re.search(r"relate_oracle|oracleload|refload|librelate_ref|orc_[a-z_]+\(", t):
                     bad.append(os.path.join(dp_, f))
     assert not bad, bad
+
+
+def test_host_cli_builds_and_fails_loudly_without_gpu(tmp_path):
+    """relate_amd/relateHMM_hip (reference CLI flags over the C ABI): usage without arguments; with data but no
+    GPU it must stop with the library's error, not fall back to anything."""
+    import subprocess
+    import torch
+    cli = os.path.join(ROOT, "relate_amd", "relateHMM_hip")
+    assert os.path.exists(cli), "run __graft_entry__.build()"
+    r = subprocess.run([cli], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "SYNTAX" in r.stdout
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    data = os.path.join(ROOT, "tests", "golden", "data")
+    r = subprocess.run([cli, "-o", data + "/options.linkage.txt", "-file", data + "/dat_small", "-v", "0"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1
+    assert "no HIP device" in r.stderr or "no CPU fallback" in r.stderr
