@@ -350,7 +350,7 @@ like_combine_kernel(ChunkOut O, const double *__restrict__ params, int nlanes, i
 }
 
 // ---- K6 ----------------------------------------------------------------------------------------------------
-// Normalised forward vectors go to three planes fwd[(r * M + s) * P + p]; the boundary vectors of the chunked sweep:
+// Forward checkpoints (one vector per 8-SNP tile) go to three planes; the boundary vectors of the chunked sweep:
 // astart[(c * nlp + p) * 3 ..] = forward vector entering chunk c, bend[...] = backward vector at the last SNP of
 // chunk c.  Any positive scale factor cancels in the posterior, so vectors are normalised with v_rcp_f64.
 __device__ inline void norm_fast(double &x0, double &x1, double &x2) {
@@ -395,24 +395,37 @@ decode_combine_kernel(ChunkOut O, const double *__restrict__ params, int P, int 
   }
 }
 
+// Posterior tiles.  decode works on tiles of kTile = 8 SNPs (chunk starts are multiples of 8): the forward pass
+// stores only the normalised vector ENTERING every tile (3 doubles per 8 SNPs); the backward pass recomputes the 8
+// forward vectors of a tile from that checkpoint while it holds the tile's records anyway.  Recomputing costs
+// ~35 FP64 instructions per step in an HBM-bound kernel and removes 42 of the 136 bytes per (pair, SNP) that a
+// stored forward matrix costs.
+static constexpr int kTile = 8;
+static constexpr int kTilePad = kTile + 1;
+
 template <bool DR, int TIER>
-__device__ inline void dec_fwd_group(const LaneC &C, const EmisRec (&A)[kGroup], double (&x)[1][3], int &m,
-                                     double *__restrict__ o, size_t stride, size_t plane) {
+__device__ inline void dec_fwd_group(const LaneC &C, const EmisRec (&A)[kGroup], double (&x)[1][3], int &m) {
 #pragma unroll
   for (int u = 0; u < kGroup; u++) {
     fwd_step<1, DR, TIER>(C, A[u], x);
-    norm_fast(x[0][0], x[0][1], x[0][2]);
     m += rec_dropped(A[u]) ? 0 : 1;
-    double *q = o + (size_t)u * stride;
-    q[0] = x[0][0]; q[plane] = x[0][1]; q[2 * plane] = x[0][2];
   }
 }
+template <bool DR>
+__device__ inline void dec_fwd_dispatch(const LaneC &C, const EmisRec (&A)[kGroup], double (&x)[1][3], int &m) {
+  int tier = group_tier<kGroup>(C, A);
+  if (tier == 0) dec_fwd_group<DR, 0>(C, A, x, m);
+  else if (tier == 1) dec_fwd_group<DR, 1>(C, A, x, m);
+  else dec_fwd_group<DR, 2>(C, A, x, m);
+}
 
-// forward sweep inside one chunk; workgroup = 256 pairs of one chunk; astart == nullptr means nchunk == 1
+// forward sweep inside one chunk; workgroup = 256 pairs of one chunk; astart == nullptr means nchunk == 1.
+// ckpt[(r * ntile + tile) * P + p], tile = s / 8: vector entering the tile.
 template <bool DR>
 __global__ void __launch_bounds__(256)
 decode_fwd_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *__restrict__ params, int nlp,
-                  int chunk_len, const double *__restrict__ astart, double *__restrict__ fwd, int *__restrict__ nsnp) {
+                  int chunk_len, const double *__restrict__ astart, double *__restrict__ ckpt, int *__restrict__ nsnp) {
+  static_assert(2 * kGroup == kTile, "one loop iteration = one tile");
   int bpc = nlp / 256;
   int c = blockIdx.x / bpc;
   int p = (blockIdx.x % bpc) * 256 + threadIdx.x;
@@ -426,43 +439,39 @@ decode_fwd_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *_
     size_t at = ((size_t)c * nlp + p) * 3;
     x[0][0] = astart[at]; x[0][1] = astart[at + 1]; x[0][2] = astart[at + 2];
   }
-  const size_t stride = (size_t)P, plane = (size_t)M * P;
+  const size_t stride = (size_t)P;
+  const size_t plane = (size_t)((M + kTile - 1) / kTile) * P;
   const EmisRec *col = rec + p;
-  double *fcol = fwd + p;
+  double *kcol = ckpt + p;
   int m = 0;
   int s = sb;
   EmisRec A[kGroup], B[kGroup];
-  if (s + 2 * kGroup <= se) {
+  if (s + kTile <= se) {
 #pragma unroll
     for (int u = 0; u < kGroup; u++) A[u] = col[(size_t)(s + u) * stride];
   }
-  for (; s + 2 * kGroup <= se; s += 2 * kGroup) {
+  for (; s + kTile <= se; s += kTile) {
 #pragma unroll
     for (int u = 0; u < kGroup; u++) B[u] = col[(size_t)(s + kGroup + u) * stride];
-    {
-      int tier = group_tier<kGroup>(C, A);
-      double *o = fcol + (size_t)s * stride;
-      if (tier == 0) dec_fwd_group<DR, 0>(C, A, x, m, o, stride, plane);
-      else if (tier == 1) dec_fwd_group<DR, 1>(C, A, x, m, o, stride, plane);
-      else dec_fwd_group<DR, 2>(C, A, x, m, o, stride, plane);
-    }
-#pragma unroll
-    for (int u = 0; u < kGroup; u++) A[u] = col[(size_t)min(s + 2 * kGroup + u, M - 1) * stride];
-    {
-      int tier = group_tier<kGroup>(C, B);
-      double *o = fcol + (size_t)(s + kGroup) * stride;
-      if (tier == 0) dec_fwd_group<DR, 0>(C, B, x, m, o, stride, plane);
-      else if (tier == 1) dec_fwd_group<DR, 1>(C, B, x, m, o, stride, plane);
-      else dec_fwd_group<DR, 2>(C, B, x, m, o, stride, plane);
-    }
-  }
-  for (; s < se; s++) {
-    EmisRec r = col[(size_t)s * stride];
-    fwd_step<1, DR, 2>(C, r, x);
     norm_fast(x[0][0], x[0][1], x[0][2]);
-    m += rec_dropped(r) ? 0 : 1;
-    double *q = fcol + (size_t)s * stride;
+    {
+      double *q = kcol + (size_t)(s / kTile) * stride;
+      q[0] = x[0][0]; q[plane] = x[0][1]; q[2 * plane] = x[0][2];
+    }
+    dec_fwd_dispatch<DR>(C, A, x, m);
+#pragma unroll
+    for (int u = 0; u < kGroup; u++) A[u] = col[(size_t)min(s + kTile + u, M - 1) * stride];
+    dec_fwd_dispatch<DR>(C, B, x, m);
+  }
+  if (s < se) {  // ragged last tile of the matrix
+    norm_fast(x[0][0], x[0][1], x[0][2]);
+    double *q = kcol + (size_t)(s / kTile) * stride;
     q[0] = x[0][0]; q[plane] = x[0][1]; q[2 * plane] = x[0][2];
+    for (; s < se; s++) {
+      EmisRec r = col[(size_t)s * stride];
+      fwd_step<1, DR, 2>(C, r, x);
+      m += rec_dropped(r) ? 0 : 1;
+    }
   }
   if (nsnp) atomicAdd(&nsnp[p], m);
 }
@@ -472,12 +481,18 @@ decode_fwd_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *_
 // posterior_x(s) = fwd_x(s) bwd_x(s) / sum_y fwd_y(s) bwd_y(s): every scale factor cancels.
 // Lanes hold consecutive pairs, whose posterior rows lie 3*M doubles apart: results of kTile SNPs are transposed
 // through LDS so that every pair row is written in 64-byte pieces.
-static constexpr int kTile = 8;
-static constexpr int kTilePad = kTile + 1;
-
 template <bool DR, int TIER>
-__device__ inline void dec_bwd_tile(const LaneC &C, const EmisRec (&R)[kTile], const double (&F)[kTile][3], int tb,
+__device__ inline void dec_bwd_tile(const LaneC &C, const EmisRec (&R)[kTile], double f0, double f1, double f2, int tb,
                                     int te, double &b0, double &b1, double &b2, double (&tile)[3][256][kTilePad]) {
+  double F[kTile][3];
+  {
+    double x[1][3] = {{f0, f1, f2}};
+#pragma unroll
+    for (int u = 0; u < kTile; u++) {
+      fwd_step<1, DR, TIER>(C, R[u], x);
+      F[u][0] = x[0][0]; F[u][1] = x[0][1]; F[u][2] = x[0][2];
+    }
+  }
 #pragma unroll
   for (int u = kTile - 1; u >= 0; u--) {
     if (tb + u >= te) continue;  // uniform
@@ -498,7 +513,7 @@ __device__ inline void dec_bwd_tile(const LaneC &C, const EmisRec (&R)[kTile], c
 template <bool DR>
 __global__ void __launch_bounds__(256)
 decode_bwd_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *__restrict__ params, int nlp,
-                  int chunk_len, const double *__restrict__ bend, const double *__restrict__ fwd,
+                  int chunk_len, const double *__restrict__ bend, const double *__restrict__ ckpt,
                   double *__restrict__ post) {
   __shared__ double tile[3][256][kTilePad];
   int bpc = nlp / 256;
@@ -515,22 +530,22 @@ decode_bwd_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *_
     size_t at = ((size_t)c * nlp + pc) * 3;
     b0 = bend[at]; b1 = bend[at + 1]; b2 = bend[at + 2];
   }
-  const size_t stride = (size_t)P, plane = (size_t)M * P;
+  const size_t stride = (size_t)P;
+  const size_t plane = (size_t)((M + kTile - 1) / kTile) * P;
   for (int tb = (se - 1) & ~(kTile - 1); tb >= sb; tb -= kTile) {
     int te = min(se, tb + kTile);
     EmisRec R[kTile];
-    double F[kTile][3];
 #pragma unroll
     for (int u = 0; u < kTile; u++) {
       int s = min(tb + u, te - 1);
       R[u] = rec[(size_t)s * stride + pc];
-      const double *f = fwd + (size_t)s * stride + pc;
-      F[u][0] = f[0]; F[u][1] = f[plane]; F[u][2] = f[2 * plane];
     }
+    const double *f = ckpt + (size_t)(tb / kTile) * stride + pc;
+    double f0 = f[0], f1 = f[plane], f2 = f[2 * plane];
     int tier = group_tier<kTile>(C, R);
-    if (tier == 0) dec_bwd_tile<DR, 0>(C, R, F, tb, te, b0, b1, b2, tile);
-    else if (tier == 1) dec_bwd_tile<DR, 1>(C, R, F, tb, te, b0, b1, b2, tile);
-    else dec_bwd_tile<DR, 2>(C, R, F, tb, te, b0, b1, b2, tile);
+    if (tier == 0) dec_bwd_tile<DR, 0>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
+    else if (tier == 1) dec_bwd_tile<DR, 1>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
+    else dec_bwd_tile<DR, 2>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
     __syncthreads();
     // 3 x 256 x kTile values; consecutive threads write consecutive SNPs of one pair row
 #pragma unroll

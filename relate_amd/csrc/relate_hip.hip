@@ -75,7 +75,7 @@ struct relate_hip_ctx {
   // device: work
   DBuf<int32_t> dLanePair;
   DBuf<double> dParams, dOut, dPost;
-  DBuf<double> dFwd;  // 3 planes x M x P normalised forward vectors
+  DBuf<double> dFwd;  // 3 planes x ceil(M/8) x P forward checkpoints (one per posterior tile)
   DBuf<uint8_t> dBp;
   DBuf<int8_t> dPath;
   DBuf<int> dNsnp;
@@ -475,7 +475,7 @@ int decode_block(relate_hip_t h, int P, const double *params, double *post, int8
   HIPCHK(h, hipMemcpyAsync(h->dParams.p, params, sizeof(double) * 3 * P, hipMemcpyHostToDevice, h->stream));
   bool ran = false;
   if (post || nsnp_out || !copy_back) {
-    HIPCHK(h, h->dFwd.ensure((size_t)3 * M * P));
+    HIPCHK(h, h->dFwd.ensure((size_t)3 * ((M + 7) / 8) * P));
     HIPCHK(h, h->dPost.ensure((size_t)3 * M * P));
     int rc = launch_decode(h, P);
     if (rc) return rc;
@@ -866,7 +866,7 @@ int relate_hip_decode(relate_hip_t h, const int32_t *pairs, int P, const double 
   if (rc) return rc;
   if (!pairs || !params || P < 0) return fail(h, RELATE_E_ARG, "bad arguments");
   h->timings[2] = h->timings[3] = 0;
-  size_t lim = pair_block_limit(h, sizeof(EmisRec) + 6 * sizeof(double) + 2);
+  size_t lim = pair_block_limit(h, sizeof(EmisRec) + 3 * sizeof(double) + 5);
   for (long b0 = 0; b0 < P; b0 += (long)lim) {
     int pb = (int)std::min<long>((long)lim, P - b0);
     rc = stage_block(h, pairs + 2 * b0, pb);
@@ -884,7 +884,7 @@ int relate_hip_run_pairs(relate_hip_t h, const int32_t *pairs, int P, const doub
   if (rc) return rc;
   if (!pairs || !out || P < 0) return fail(h, RELATE_E_ARG, "bad arguments");
   h->timings[1] = h->timings[2] = h->timings[3] = 0;
-  size_t lim = pair_block_limit(h, sizeof(EmisRec) + 6 * sizeof(double) + 2);
+  size_t lim = pair_block_limit(h, sizeof(EmisRec) + 3 * sizeof(double) + 5);
   std::vector<double> par;
   std::vector<int> ns;
   for (long b0 = 0; b0 < P; b0 += (long)lim) {
