@@ -227,33 +227,51 @@ __device__ inline void fwd_group(const LaneC &C, const EmisRec (&R)[kGroup], dou
   else fwd_group_t<NV, DR, 2>(C, R, x);
 }
 
-// Streams rows [sb, se) of column `col` (row stride P records) through fwd_step for NV vectors.
+// Streams the records of rows [sb, se) of one column (row stride `stride` records) through two callbacks: groups of
+// kGroup records (the bulk) and single records (a tail of < NBUF * kGroup rows).  NBUF groups are in flight per lane
+// in a statically indexed register ring, so a wave always has (NBUF - 1) * 128 B per lane on the way from HBM while it
+// computes: with 2-3 waves per SIMD that covers the ~2 us loaded HBM latency.
+template <int NBUF, class FG, class FT>
+__device__ inline void stream_records(const EmisRec *__restrict__ col, size_t stride, int sb, int se, int M, FG &&on_group,
+                                      FT &&on_tail) {
+  constexpr int span = NBUF * kGroup;
+  int s = sb;
+  EmisRec buf[NBUF][kGroup];
+  if (s + span <= se) {
+#pragma unroll
+    for (int j = 0; j < NBUF; j++)
+#pragma unroll
+      for (int u = 0; u < kGroup; u++) buf[j][u] = col[(size_t)(s + j * kGroup + u) * stride];
+  }
+  for (; s + span <= se; s += span) {
+#pragma unroll
+    for (int j = 0; j < NBUF; j++) {
+      on_group(buf[j], s + j * kGroup);
+      // refill with the group one ring turn ahead; clamped to the last row of the matrix so that a prefetch past the
+      // end (discarded) stays a valid address
+#pragma unroll
+      for (int u = 0; u < kGroup; u++) buf[j][u] = col[(size_t)min(s + span + j * kGroup + u, M - 1) * stride];
+    }
+  }
+  for (; s < se; s++) on_tail(col[(size_t)s * stride], s);
+}
+
+static constexpr int kNbuf = 2;  // measured: 4 costs occupancy (216 vs 152 VGPRs) and gains nothing at 5 TB/s
+
+// forward recursion over rows [sb, se) for NV vectors
 template <int NV, bool DR>
 __device__ inline void sweep(const EmisRec *__restrict__ rec, int P, int lp, int sb, int se, int M, const LaneC &C,
                              double (&x)[NV][3], int (&ex)[NV]) {
-  const size_t stride = (size_t)P;
-  const EmisRec *col = rec + lp;
-  int s = sb;
-  EmisRec A[kGroup], B[kGroup];
-  if (s + 2 * kGroup <= se) {
+  stream_records<kNbuf>(
+      rec + lp, (size_t)P, sb, se, M,
+      [&](const EmisRec(&R)[kGroup], int s) {
+        fwd_group<NV, DR>(C, R, x);
+        if (s & kGroup) {  // every second group: 8 steps between renormalisations
 #pragma unroll
-    for (int u = 0; u < kGroup; u++) A[u] = col[(size_t)(s + u) * stride];
-  }
-  for (; s + 2 * kGroup <= se; s += 2 * kGroup) {
-#pragma unroll
-    for (int u = 0; u < kGroup; u++) B[u] = col[(size_t)(s + kGroup + u) * stride];
-    fwd_group<NV, DR>(C, A, x);
-    // next group; clamped to the last row of the matrix so that a prefetch past the end (discarded) stays valid
-#pragma unroll
-    for (int u = 0; u < kGroup; u++) A[u] = col[(size_t)min(s + 2 * kGroup + u, M - 1) * stride];
-    fwd_group<NV, DR>(C, B, x);
-#pragma unroll
-    for (int v = 0; v < NV; v++) ex[v] += rescale3(x[v][0], x[v][1], x[v][2]);
-  }
-  for (; s < se; s++) {
-    EmisRec r = col[(size_t)s * stride];
-    fwd_step<NV, DR, 2>(C, r, x);
-  }
+          for (int v = 0; v < NV; v++) ex[v] += rescale3(x[v][0], x[v][1], x[v][2]);
+        }
+      },
+      [&](const EmisRec &r, int) { fwd_step<NV, DR, 2>(C, r, x); });
 #pragma unroll
   for (int v = 0; v < NV; v++) ex[v] += rescale3(x[v][0], x[v][1], x[v][2]);
 }
@@ -395,13 +413,14 @@ decode_combine_kernel(ChunkOut O, const double *__restrict__ params, int P, int 
   }
 }
 
-// Posterior tiles.  decode works on tiles of kTile = 8 SNPs (chunk starts are multiples of 8): the forward pass
-// stores only the normalised vector ENTERING every tile (3 doubles per 8 SNPs); the backward pass recomputes the 8
-// forward vectors of a tile from that checkpoint while it holds the tile's records anyway.  Recomputing costs
-// ~35 FP64 instructions per step in an HBM-bound kernel and removes 42 of the 136 bytes per (pair, SNP) that a
-// stored forward matrix costs.
-static constexpr int kTile = 8;
+// Posterior tiles.  The backward pass works on tiles of kTile = 16 SNPs (chunk starts are multiples of 16) made of
+// four groups of kGroup = 4: the forward pass stores only the normalised vector ENTERING every half tile (3
+// doubles per 4 SNPs); the backward pass recomputes the 4 forward vectors of a half tile from that checkpoint
+// while it holds the records anyway.  Recomputing costs ~35 FP64 instructions per step in an HBM-bound kernel and
+// removes 36 of the 136 bytes per (pair, SNP) that a stored forward matrix costs.
+static constexpr int kTile = 16;
 static constexpr int kTilePad = kTile + 1;
+static constexpr int kBwdThreads = 64;  // one wave per workgroup: 13.5 KiB of LDS each, up to 11 per CU
 
 template <bool DR, int TIER>
 __device__ inline void dec_fwd_group(const LaneC &C, const EmisRec (&A)[kGroup], double (&x)[1][3], int &m) {
@@ -418,14 +437,17 @@ __device__ inline void dec_fwd_dispatch(const LaneC &C, const EmisRec (&A)[kGrou
   else if (tier == 1) dec_fwd_group<DR, 1>(C, A, x, m);
   else dec_fwd_group<DR, 2>(C, A, x, m);
 }
+__device__ inline void put_ckpt(double *__restrict__ q, size_t plane, double (&x)[1][3]) {
+  norm_fast(x[0][0], x[0][1], x[0][2]);
+  q[0] = x[0][0]; q[plane] = x[0][1]; q[2 * plane] = x[0][2];
+}
 
 // forward sweep inside one chunk; workgroup = 256 pairs of one chunk; astart == nullptr means nchunk == 1.
-// ckpt[(r * ntile + tile) * P + p], tile = s / 8: vector entering the tile.
+// ckpt[(r * nhalf + s / 4) * P + p]: vector entering the half tile that starts at SNP s.
 template <bool DR>
 __global__ void __launch_bounds__(256)
 decode_fwd_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *__restrict__ params, int nlp,
                   int chunk_len, const double *__restrict__ astart, double *__restrict__ ckpt, int *__restrict__ nsnp) {
-  static_assert(2 * kGroup == kTile, "one loop iteration = one tile");
   int bpc = nlp / 256;
   int c = blockIdx.x / bpc;
   int p = (blockIdx.x % bpc) * 256 + threadIdx.x;
@@ -440,39 +462,20 @@ decode_fwd_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *_
     x[0][0] = astart[at]; x[0][1] = astart[at + 1]; x[0][2] = astart[at + 2];
   }
   const size_t stride = (size_t)P;
-  const size_t plane = (size_t)((M + kTile - 1) / kTile) * P;
-  const EmisRec *col = rec + p;
+  const size_t plane = (size_t)((M + kGroup - 1) / kGroup) * P;
   double *kcol = ckpt + p;
   int m = 0;
-  int s = sb;
-  EmisRec A[kGroup], B[kGroup];
-  if (s + kTile <= se) {
-#pragma unroll
-    for (int u = 0; u < kGroup; u++) A[u] = col[(size_t)(s + u) * stride];
-  }
-  for (; s + kTile <= se; s += kTile) {
-#pragma unroll
-    for (int u = 0; u < kGroup; u++) B[u] = col[(size_t)(s + kGroup + u) * stride];
-    norm_fast(x[0][0], x[0][1], x[0][2]);
-    {
-      double *q = kcol + (size_t)(s / kTile) * stride;
-      q[0] = x[0][0]; q[plane] = x[0][1]; q[2 * plane] = x[0][2];
-    }
-    dec_fwd_dispatch<DR>(C, A, x, m);
-#pragma unroll
-    for (int u = 0; u < kGroup; u++) A[u] = col[(size_t)min(s + kTile + u, M - 1) * stride];
-    dec_fwd_dispatch<DR>(C, B, x, m);
-  }
-  if (s < se) {  // ragged last tile of the matrix
-    norm_fast(x[0][0], x[0][1], x[0][2]);
-    double *q = kcol + (size_t)(s / kTile) * stride;
-    q[0] = x[0][0]; q[plane] = x[0][1]; q[2 * plane] = x[0][2];
-    for (; s < se; s++) {
-      EmisRec r = col[(size_t)s * stride];
-      fwd_step<1, DR, 2>(C, r, x);
-      m += rec_dropped(r) ? 0 : 1;
-    }
-  }
+  stream_records<kNbuf>(
+      rec + p, stride, sb, se, M,
+      [&](const EmisRec(&R)[kGroup], int s) {
+        put_ckpt(kcol + (size_t)(s / kGroup) * stride, plane, x);
+        dec_fwd_dispatch<DR>(C, R, x, m);
+      },
+      [&](const EmisRec &r, int s) {
+        if ((s & (kGroup - 1)) == 0) put_ckpt(kcol + (size_t)(s / kGroup) * stride, plane, x);
+        fwd_step<1, DR, 2>(C, r, x);
+        m += rec_dropped(r) ? 0 : 1;
+      });
   if (nsnp) atomicAdd(&nsnp[p], m);
 }
 
@@ -480,45 +483,47 @@ decode_fwd_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *_
 // IBD2, row1 IBD1, row2 IBD0 (decodek2, :1133-1137); -1 where the SNP is dropped (.post writer, :126-133).
 // posterior_x(s) = fwd_x(s) bwd_x(s) / sum_y fwd_y(s) bwd_y(s): every scale factor cancels.
 // Lanes hold consecutive pairs, whose posterior rows lie 3*M doubles apart: results of kTile SNPs are transposed
-// through LDS so that every pair row is written in 64-byte pieces.
+// through LDS so that every pair row is written in whole 128-byte lines (64-byte pieces from 8-SNP tiles left
+// half-written lines in L2 and cost DRAM efficiency).  Workgroup = one wave = 64 pairs of one chunk.
 template <bool DR, int TIER>
-__device__ inline void dec_bwd_tile(const LaneC &C, const EmisRec (&R)[kTile], double f0, double f1, double f2, int tb,
-                                    int te, double &b0, double &b1, double &b2, double (&tile)[3][256][kTilePad]) {
-  double F[kTile][3];
+__device__ inline void dec_bwd_half(const LaneC &C, const EmisRec (&R)[kGroup], double f0, double f1, double f2, int hb,
+                                    int te, int toff, double &b0, double &b1, double &b2,
+                                    double (&tile)[3][kBwdThreads][kTilePad]) {
+  double F[kGroup][3];
   {
     double x[1][3] = {{f0, f1, f2}};
 #pragma unroll
-    for (int u = 0; u < kTile; u++) {
+    for (int u = 0; u < kGroup; u++) {
       fwd_step<1, DR, TIER>(C, R[u], x);
       F[u][0] = x[0][0]; F[u][1] = x[0][1]; F[u][2] = x[0][2];
     }
   }
 #pragma unroll
-  for (int u = kTile - 1; u >= 0; u--) {
-    if (tb + u >= te) continue;  // uniform
+  for (int u = kGroup - 1; u >= 0; u--) {
+    if (hb + u >= te) continue;  // uniform
     double p0 = F[u][0] * b0, p1 = F[u][1] * b1, p2 = F[u][2] * b2;
     double sum = (p0 + p1) + p2;
     double inv = __builtin_amdgcn_rcp(sum);
     inv = inv * __builtin_fma(-sum, inv, 2.0);
     inv = inv * __builtin_fma(-sum, inv, 2.0);
     bool dr = rec_dropped(R[u]);
-    tile[2][threadIdx.x][u] = dr ? -1.0 : p0 * inv;  // row2 = IBD0
-    tile[1][threadIdx.x][u] = dr ? -1.0 : p1 * inv;
-    tile[0][threadIdx.x][u] = dr ? -1.0 : p2 * inv;  // row0 = IBD2
+    tile[2][threadIdx.x][toff + u] = dr ? -1.0 : p0 * inv;  // row2 = IBD0
+    tile[1][threadIdx.x][toff + u] = dr ? -1.0 : p1 * inv;
+    tile[0][threadIdx.x][toff + u] = dr ? -1.0 : p2 * inv;  // row0 = IBD2
     bwd_step<DR, TIER>(C, R[u], b0, b1, b2);
     norm_fast(b0, b1, b2);
   }
 }
 
 template <bool DR>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kBwdThreads)
 decode_bwd_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *__restrict__ params, int nlp,
                   int chunk_len, const double *__restrict__ bend, const double *__restrict__ ckpt,
                   double *__restrict__ post) {
-  __shared__ double tile[3][256][kTilePad];
-  int bpc = nlp / 256;
+  __shared__ double tile[3][kBwdThreads][kTilePad];
+  int bpc = (P + kBwdThreads - 1) / kBwdThreads;
   int c = blockIdx.x / bpc;
-  int pbase = (blockIdx.x % bpc) * 256;
+  int pbase = (blockIdx.x % bpc) * kBwdThreads;
   int p = pbase + threadIdx.x;
   int pc = p < P ? p : P - 1;  // dead lanes shadow a valid pair and write nothing
   double a = params[3 * pc], k2 = params[3 * pc + 1], k1 = params[3 * pc + 2];
@@ -531,27 +536,29 @@ decode_bwd_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *_
     b0 = bend[at]; b1 = bend[at + 1]; b2 = bend[at + 2];
   }
   const size_t stride = (size_t)P;
-  const size_t plane = (size_t)((M + kTile - 1) / kTile) * P;
+  const size_t plane = (size_t)((M + kGroup - 1) / kGroup) * P;
   for (int tb = (se - 1) & ~(kTile - 1); tb >= sb; tb -= kTile) {
     int te = min(se, tb + kTile);
-    EmisRec R[kTile];
 #pragma unroll
-    for (int u = 0; u < kTile; u++) {
-      int s = min(tb + u, te - 1);
-      R[u] = rec[(size_t)s * stride + pc];
+    for (int part = kTile / kGroup - 1; part >= 0; part--) {
+      int hb = tb + part * kGroup;
+      if (hb >= te) continue;  // uniform: ragged last tile
+      EmisRec R[kGroup];
+#pragma unroll
+      for (int u = 0; u < kGroup; u++) R[u] = rec[(size_t)min(hb + u, te - 1) * stride + pc];
+      const double *f = ckpt + (size_t)(hb / kGroup) * stride + pc;
+      double f0 = f[0], f1 = f[plane], f2 = f[2 * plane];
+      int tier = group_tier<kGroup>(C, R);
+      if (tier == 0) dec_bwd_half<DR, 0>(C, R, f0, f1, f2, hb, te, part * kGroup, b0, b1, b2, tile);
+      else if (tier == 1) dec_bwd_half<DR, 1>(C, R, f0, f1, f2, hb, te, part * kGroup, b0, b1, b2, tile);
+      else dec_bwd_half<DR, 2>(C, R, f0, f1, f2, hb, te, part * kGroup, b0, b1, b2, tile);
     }
-    const double *f = ckpt + (size_t)(tb / kTile) * stride + pc;
-    double f0 = f[0], f1 = f[plane], f2 = f[2 * plane];
-    int tier = group_tier<kTile>(C, R);
-    if (tier == 0) dec_bwd_tile<DR, 0>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
-    else if (tier == 1) dec_bwd_tile<DR, 1>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
-    else dec_bwd_tile<DR, 2>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
     __syncthreads();
-    // 3 x 256 x kTile values; consecutive threads write consecutive SNPs of one pair row
+    // 3 x 64 x kTile values; consecutive threads write consecutive SNPs of one pair row (128-byte pieces)
 #pragma unroll
     for (int j = 0; j < 3 * kTile; j++) {
-      int idx = j * 256 + threadIdx.x;
-      int e = idx & (kTile - 1), pr = (idx >> 3) & 255, r = idx >> 11;
+      int idx = j * kBwdThreads + threadIdx.x;
+      int e = idx % kTile, pr = (idx / kTile) % kBwdThreads, r = idx / (kTile * kBwdThreads);
       int s = tb + e, pp = pbase + pr;
       if (s < te && pp < P) post[((size_t)pp * 3 + r) * M + s] = tile[r][pr][e];
     }

@@ -75,7 +75,7 @@ struct relate_hip_ctx {
   // device: work
   DBuf<int32_t> dLanePair;
   DBuf<double> dParams, dOut, dPost;
-  DBuf<double> dFwd;  // 3 planes x ceil(M/8) x P forward checkpoints (one per posterior tile)
+  DBuf<double> dFwd;  // 3 planes x ceil(M/4) x P forward checkpoints (one per half tile)
   DBuf<uint8_t> dBp;
   DBuf<int8_t> dPath;
   DBuf<int> dNsnp;
@@ -160,7 +160,7 @@ int stage_block(relate_hip_t h, const int32_t *pairs, int P) {
 
 // SNP-axis chunking.  A sweep lane carries a serial chain of M steps; below about two waves per SIMD the
 // machine idles, so the SNP axis is cut until there are enough threads -- but a chunked step costs ~1.5x a plain
-// one, so a launch that already has >= ~1.5 waves per SIMD stays a single sweep.  Chunks are multiples of 8 SNPs
+// one, so a launch that already has >= ~1.5 waves per SIMD stays a single sweep.  Chunks are multiples of 16 SNPs
 // (the posterior tiles of decode_bwd_kernel) and at least 256 SNPs long.
 void pick_chunks(int M, long lanes, int *nchunk, int *chunk_len) {
   const long simd_lanes = 256L * 4 * 64;  // one wave on every SIMD
@@ -173,7 +173,7 @@ void pick_chunks(int M, long lanes, int *nchunk, int *chunk_len) {
   if (c > cmax) c = cmax;
   if (c < 1) c = 1;
   int len = (int)((M + c - 1) / c);
-  len = (len + 7) / 8 * 8;
+  len = (len + 15) / 16 * 16;
   *chunk_len = len;
   *nchunk = (M + len - 1) / len;
 }
@@ -456,12 +456,13 @@ int launch_decode(relate_hip_t h, int P) {
                        clen, astart, h->dFwd.p, h->dNsnp.p);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+  dim3 bgrid((unsigned)((size_t)((P + kBwdThreads - 1) / kBwdThreads) * nchunk));
   if (dr)
-    hipLaunchKernelGGL(decode_bwd_kernel<true>, grid, dim3(256), 0, h->stream, h->dRec.p, M, P, h->dParams.p, nlp, clen,
-                       bend, h->dFwd.p, h->dPost.p);
+    hipLaunchKernelGGL(decode_bwd_kernel<true>, bgrid, dim3(kBwdThreads), 0, h->stream, h->dRec.p, M, P, h->dParams.p,
+                       nlp, clen, bend, h->dFwd.p, h->dPost.p);
   else
-    hipLaunchKernelGGL(decode_bwd_kernel<false>, grid, dim3(256), 0, h->stream, h->dRec.p, M, P, h->dParams.p, nlp,
-                       clen, bend, h->dFwd.p, h->dPost.p);
+    hipLaunchKernelGGL(decode_bwd_kernel<false>, bgrid, dim3(kBwdThreads), 0, h->stream, h->dRec.p, M, P,
+                       h->dParams.p, nlp, clen, bend, h->dFwd.p, h->dPost.p);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
   return 0;
@@ -475,7 +476,7 @@ int decode_block(relate_hip_t h, int P, const double *params, double *post, int8
   HIPCHK(h, hipMemcpyAsync(h->dParams.p, params, sizeof(double) * 3 * P, hipMemcpyHostToDevice, h->stream));
   bool ran = false;
   if (post || nsnp_out || !copy_back) {
-    HIPCHK(h, h->dFwd.ensure((size_t)3 * ((M + 7) / 8) * P));
+    HIPCHK(h, h->dFwd.ensure((size_t)3 * ((M + 3) / 4) * P));
     HIPCHK(h, h->dPost.ensure((size_t)3 * M * P));
     int rc = launch_decode(h, P);
     if (rc) return rc;
@@ -866,7 +867,7 @@ int relate_hip_decode(relate_hip_t h, const int32_t *pairs, int P, const double 
   if (rc) return rc;
   if (!pairs || !params || P < 0) return fail(h, RELATE_E_ARG, "bad arguments");
   h->timings[2] = h->timings[3] = 0;
-  size_t lim = pair_block_limit(h, sizeof(EmisRec) + 3 * sizeof(double) + 5);
+  size_t lim = pair_block_limit(h, sizeof(EmisRec) + 3 * sizeof(double) + 8);
   for (long b0 = 0; b0 < P; b0 += (long)lim) {
     int pb = (int)std::min<long>((long)lim, P - b0);
     rc = stage_block(h, pairs + 2 * b0, pb);
@@ -884,7 +885,7 @@ int relate_hip_run_pairs(relate_hip_t h, const int32_t *pairs, int P, const doub
   if (rc) return rc;
   if (!pairs || !out || P < 0) return fail(h, RELATE_E_ARG, "bad arguments");
   h->timings[1] = h->timings[2] = h->timings[3] = 0;
-  size_t lim = pair_block_limit(h, sizeof(EmisRec) + 3 * sizeof(double) + 5);
+  size_t lim = pair_block_limit(h, sizeof(EmisRec) + 3 * sizeof(double) + 8);
   std::vector<double> par;
   std::vector<int> ns;
   for (long b0 = 0; b0 < P; b0 += (long)lim) {
