@@ -28,14 +28,37 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP64_PEAK_TFLOPS = 78.6    # vector FP64 (half the 157.3 TF FP32 vector rate)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s achievable)
 
-# algorithmic bytes per (pair, SNP) of one launch (DESIGN.md "Kernels"): emission record 32 B; forward vector 24 B;
-# posterior 24 B; packed genotypes 2 x 2 bit.
-BYTES = {"stage": 32.0 + 0.5, "like": 32.0, "decode_fwd": 32.0 + 24.0, "decode_bwd": 32.0 + 24.0 + 24.0}
-# FP64 operations per lane-step counted from the kernel source (2 exp at ~22 flop each + transitions + 3x3 update)
-FLOP_PER_STEP = 2 * 22 + 22 + 18
+# Algorithmic bytes per (pair, SNP) of one launch: emission record 32 B; packed genotypes
+# 2 x 2 bit; forward checkpoint 3 doubles per 4 SNPs = 6 B; posterior 3 x 8 B.  A launch that is cut along the SNP
+# axis adds the chunk-product pass, which reads the records once more.
+def algorithmic_bytes(like_chunks, decode_chunks):
+    return {"stage": 32.0 + 0.5,
+            "like": 32.0,
+            "decode_fwd": (32.0 if decode_chunks > 1 else 0.0) + 32.0 + 6.0,
+            "decode_bwd": 32.0 + 6.0 + 24.0}
+
+
+# FP64 VALU instructions per lane-step of the likelihood kernels, counted by rocprofv3 (SQ_INSTS_VALU / wave-steps,
+# profiles/): single sweep 36, chunk-product sweep (three row vectors) 72.  Peak = one FP64 instruction per lane per
+# 4 cycles per SIMD; measured 28.8e12 lane-FMA/s on this part (tools/ubench/fp64_ops.hip) = 57.6 TFLOP/s of FMA.
+VALU_PER_STEP = {1: 36.0, 3: 72.0}
+FP64_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9  # 39.3e12 at the 2.4 GHz boost clock
+
+
+def pmc_traffic(P, M, E):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs,
+    corrected as MI355X_MICROARCH.md prescribes), valid only for the configuration they were taken on."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh)
+    except OSError:
+        return {}
+    if (t.get("P"), t.get("M"), t.get("E")) != (P, M, E):
+        return {}
+    return {k: v["hbm_bytes"] for k, v in t["kernels"].items()}
 
 
 def opts_all_pair():
@@ -193,12 +216,22 @@ def main():
         K = args.steps
         hmm_steps = float(world) * K * P * M * (E + 2)
         per = {k: v / K for k, v in sums.items()}  # average ms per launch, HIP events on the library's stream
-        units = {"stage": P * M, "like": P * M, "decode_fwd": P * M, "decode_bwd": P * M}
+        lc, dc = H.last_chunks()
+        BYTES = algorithmic_bytes(lc, dc)
+        units = P * M
+        gbs = {k: BYTES[k] * units / (per[k] * 1e-3) / 1e9 for k in per}
         dom = max(per, key=per.get)
-        ach = BYTES[dom] * units[dom] / (per[dom] * 1e-3) / 1e9
-        kernel_name = {"stage": "stage_pairs_kernel", "like": "like_kernel", "decode_fwd": "decode_fwd_kernel",
-                       "decode_bwd": "decode_bwd_kernel"}[dom]
+        kernel_name = {"stage": "stage_pairs_win_kernel",
+                       "like": "chunk_matrix_kernel" if lc > 1 else "like_kernel",
+                       "decode_fwd": "chunk_matrix_kernel + decode_fwd_kernel" if dc > 1 else "decode_fwd_kernel",
+                       "decode_bwd": "decode_bwd_kernel"}
+        traffic = pmc_traffic(P, M, E)
+        tkey = {"stage": ["relate::stage_pairs_win_kernel"], "like": ["relate::chunk_matrix_kernel<false>"],
+                "decode_fwd": ["relate::chunk_matrix_kernel<false>", "relate::decode_fwd_kernel<false>"],
+                "decode_bwd": ["relate::decode_bwd_kernel<false>"]}[dom]
+        tr = sum(traffic[k] for k in tkey) if traffic and all(k in traffic for k in tkey) else None
         like_steps_s = P * M * E / (per["like"] * 1e-3)
+        valu = VALU_PER_STEP[3 if lc > 1 else 1]
         line = {
             "metric": "pair x SNP fwd-bwd HMM steps/sec (node), all-pairs", "value": hmm_steps / dt,
             "unit": "pair*SNP HMM steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -207,17 +240,22 @@ def main():
             "config": {"workload": "config 4 synthetic all-pairs, pair block per step: %d individuals x %d SNPs "
                                    "(%d after MAF filter), %d pairs/GPU/step, E=%d like points + decode, "
                                    "options.all.pair.txt semantics (calcA, back=5)" % (args.inds, args.snps, M, P, E),
-                       "parallelism": "pair-block shards x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                         "note": "K5 is FP64-VALU/transcendental-bound by design (2 exp per lane-step); see "
-                                 "roofline_fp64 and DESIGN.md"},
-            "roofline_fp64": {"kernel": "like_kernel", "achieved": like_steps_s * FLOP_PER_STEP / 1e12,
-                              "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": like_steps_s * FLOP_PER_STEP / 1e12 / FP64_PEAK_TFLOPS,
+                       "parallelism": "pair-block shards x%d" % world,
+                       "snp_chunks": {"like": lc, "decode": dc}},
+            "roofline": {"bound": "hbm", "kernel": kernel_name[dom], "achieved": gbs[dom], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": gbs[dom] / HBM_PEAK_GBS, "traffic": tr,
+                         "algorithmic_bytes": BYTES[dom] * units,
+                         "note": "dominant = largest share of the step; traffic = HBM bytes per launch from the "
+                                 "committed PMC passes (profiles/pmc_traffic.json), null if they were taken on another "
+                                 "configuration.  The likelihood kernels are FP64-VALU-bound by design (two expm1 "
+                                 "per lane-step, 5 lanes share one 32 B record): see roofline_fp64"},
+            "roofline_fp64": {"kernel": kernel_name["like"], "valu_insts_per_lane_step": valu,
+                              "achieved": like_steps_s * valu / 1e12, "peak": FP64_LANE_OPS_PEAK / 1e12,
+                              "unit": "T lane-instructions/s", "frac": like_steps_s * valu / FP64_LANE_OPS_PEAK,
                               "lane_steps_per_s": like_steps_s},
             "kernels_ms": per,
-            "kernels_gbs": {k: BYTES[k] * units[k] / (per[k] * 1e-3) / 1e9 for k in per},
+            "kernels_gbs": gbs,
+            "kernels_hbm_frac": {k: v / HBM_PEAK_GBS for k, v in gbs.items()},
             "setup_s": {"synthetic_data": t_gen, "load_precalc": t_pre},
         }
         if world == 1 and not args.no_cpu:

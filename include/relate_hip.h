@@ -138,6 +138,9 @@ void relate_hip_shard(int64_t P, int rank, int nranks, int64_t *begin, int64_t *
 /* Device time in ms of the kernels launched by the last like / decode / pair_emissions-stage call,
  * measured with hipEvents on the library's stream: out = {stage_ms, like_ms, decode_fwd_ms, decode_bwd_ms}. */
 int relate_hip_last_timings(relate_hip_t h, double *out4);
+/* Number of SNP-axis chunks the last like / decode launch was cut into (1 = single sweep; > 1 adds the chunk-product
+ * pass): needed to state the algorithmic bytes of a launch. */
+int relate_hip_last_chunks(relate_hip_t h, int *like_chunks, int *decode_chunks);
 /* Same computation as relate_hip_like / relate_hip_decode, but on the emission block staged by the
  * previous call for the same pairs and with results left on the device: used to time kernels with
  * inputs resident in HBM.  reps = number of back-to-back launches; ms_out = average ms per launch. */

@@ -90,6 +90,7 @@ def load_library():
     L.relate_hip_shard.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.relate_hip_shard.restype = None
     L.relate_hip_last_timings.argtypes = [vp, dp]
+    L.relate_hip_last_chunks.argtypes = [vp, ip, ip]
     L.relate_hip_bench_like.argtypes = [vp, i32p, C.c_int, dp, C.c_int, C.c_int, dp]
     L.relate_hip_bench_decode.argtypes = [vp, i32p, C.c_int, dp, C.c_int, dp, dp]
     _lib = L
@@ -260,6 +261,11 @@ class Relate:
         t = np.zeros(4)
         self.L.relate_hip_last_timings(self.h, t.ctypes.data_as(dp))
         return dict(stage_ms=t[0], like_ms=t[1], decode_fwd_ms=t[2], decode_bwd_ms=t[3])
+
+    def last_chunks(self):
+        a, b = C.c_int(0), C.c_int(0)
+        self.L.relate_hip_last_chunks(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def bench_like(self, pairs, params, reps):
         p, pp = self._pairs(pairs)

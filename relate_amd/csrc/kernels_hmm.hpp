@@ -149,6 +149,21 @@ __device__ inline void fwd_step(const LaneC &C, const EmisRec &r, double (&x)[NV
   }
   OffDiag T = offdiag_at<TIER>(C, r.t);
   double a0 = T.t01 + T.t02, a1 = T.t10 + T.t12, a2 = T.t01 + T.t20;
+  if (NV > 1) {
+    // several vectors share T and S: fold the emission into the columns once (11 shared multiplies/adds), then
+    // 9 operations per vector instead of 15
+    double c00 = (1.0 - a0) * r.s0, c10 = T.t10 * r.s0, c20 = T.t20 * r.s0;
+    double c01 = T.t01 * r.s1, c11 = (1.0 - a1) * r.s1;
+    double c02 = T.t02 * r.s2, c12 = T.t12 * r.s2, c22 = (1.0 - a2) * r.s2;
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      double f0 = x[v][0], f1 = x[v][1], f2 = x[v][2];
+      x[v][0] = __builtin_fma(f2, c20, __builtin_fma(f1, c10, f0 * c00));
+      x[v][1] = __builtin_fma(f0 + f2, c01, f1 * c11);
+      x[v][2] = __builtin_fma(f2, c22, __builtin_fma(f1, c12, f0 * c02));
+    }
+    return;
+  }
 #pragma unroll
   for (int v = 0; v < NV; v++) {
     double f0 = x[v][0], f1 = x[v][1], f2 = x[v][2];

@@ -82,6 +82,7 @@ struct relate_hip_ctx {
   DBuf<double> dCm, dAstart, dBend;  // chunk products and boundary vectors of the chunked sweeps
   DBuf<int> dCe;
   double timings[4] = {0, 0, 0, 0};
+  int last_chunks[2] = {1, 1};  // SNP-axis chunks of the last like / decode launch
 };
 
 namespace {
@@ -160,16 +161,19 @@ int stage_block(relate_hip_t h, const int32_t *pairs, int P) {
 
 // SNP-axis chunking.  A sweep lane carries a serial chain of M steps; below about two waves per SIMD the
 // machine idles, so the SNP axis is cut until there are enough threads -- but a chunked step costs ~1.5x a plain
-// one, so a launch that already has >= ~1.5 waves per SIMD stays a single sweep.  Chunks are multiples of 16 SNPs
-// (the posterior tiles of decode_bwd_kernel) and at least 256 SNPs long.
-void pick_chunks(int M, long lanes, int *nchunk, int *chunk_len) {
+// one, so a launch that already has >= ~1.5 waves per SIMD stays a single sweep.  When cutting, the likelihood
+// aims for ~12 waves per SIMD: its kernels hold 2 waves per SIMD at a time, and with only a few waves per SIMD in
+// total the last, partly filled round costs up to a third of the run time.  Decode aims for 4 (its combine kernel
+// walks the chunks serially per pair and its sweeps are HBM-bound, not latency-bound).  Chunks are multiples of 16 SNPs (the posterior tiles
+// of decode_bwd_kernel) and at least 512 SNPs long.
+void pick_chunks(int M, long lanes, int waves_per_simd, int *nchunk, int *chunk_len) {
   const long simd_lanes = 256L * 4 * 64;  // one wave on every SIMD
   long c = 1;
   if (lanes < simd_lanes * 3 / 2) {
-    const long target = simd_lanes * 4;
+    const long target = simd_lanes * waves_per_simd;
     c = lanes > 0 ? (target + lanes - 1) / lanes : 1;
   }
-  long cmax = std::max(1, M / 256);
+  long cmax = std::max(1, M / 512);
   if (c > cmax) c = cmax;
   if (c < 1) c = 1;
   int len = (int)((M + c - 1) / c);
@@ -191,7 +195,8 @@ int ensure_chunk_buffers(relate_hip_t h, size_t n, ChunkOut *O) {
 // K5 launches on lanes already uploaded to dLanePair/dParams; result in dOut (device)
 int launch_like(relate_hip_t h, int P, int nl) {
   int nchunk, clen;
-  pick_chunks(h->M, nl, &nchunk, &clen);
+  pick_chunks(h->M, nl, 12, &nchunk, &clen);
+  h->last_chunks[0] = nchunk;
   const bool dr = h->o.double_recom != 0;
   if (nchunk == 1) {
     if (dr)
@@ -421,7 +426,8 @@ int fit_block(relate_hip_t h, int P, const int32_t *pairs, long pair_base, const
 int launch_decode(relate_hip_t h, int P) {
   const int M = h->M;
   int nchunk, clen;
-  pick_chunks(M, P, &nchunk, &clen);
+  pick_chunks(M, P, 4, &nchunk, &clen);
+  h->last_chunks[1] = nchunk;
   const bool dr = h->o.double_recom != 0;
   const int nlp = pad256(P);
   const double *astart = nullptr, *bend = nullptr;
@@ -943,6 +949,13 @@ void relate_hip_shard(int64_t P, int rank, int nranks, int64_t *begin, int64_t *
 int relate_hip_last_timings(relate_hip_t h, double *out4) {
   if (!h || !out4) return RELATE_E_ARG;
   for (int i = 0; i < 4; i++) out4[i] = h->timings[i];
+  return RELATE_OK;
+}
+
+int relate_hip_last_chunks(relate_hip_t h, int *like_chunks, int *decode_chunks) {
+  if (!h) return RELATE_E_ARG;
+  if (like_chunks) *like_chunks = h->last_chunks[0];
+  if (decode_chunks) *decode_chunks = h->last_chunks[1];
   return RELATE_OK;
 }
 
