@@ -310,16 +310,41 @@ __device__ inline uint32_t win2(uint64_t lo, uint64_t hi, int q) {  // 2-bit fie
   return (uint32_t)(w >> (2 * (q & 31))) & 3u;
 }
 
+// Preference order of the conditioning depths of every SNP: order[s * back2 + i] = the depths dd < min(back2, s)
+// sorted by (LD measure descending, dd ascending), 255 beyond.  getHighestId's "first strictly largest" over any
+// subset of rows is the first entry of this list that belongs to the subset.
+__global__ void ld_order_kernel(const double *__restrict__ mea, int M, int back2, uint8_t *__restrict__ order) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= M) return;
+  uint8_t *o = order + (size_t)s * back2;
+  int n = min(back2, s);
+  for (int i = 0; i < back2; i++) o[i] = 255;
+  for (int dd = 0; dd < n; dd++) {  // insertion sort, n <= 32
+    double v = mea[(size_t)dd * (M - 1) + (s - 1)];
+    int at = dd;
+    while (at > 0) {
+      double u = mea[(size_t)o[at - 1] * (M - 1) + (s - 1)];
+      if (!(v > u)) break;  // strict: equal values keep the smaller depth first
+      o[at] = o[at - 1];
+      at--;
+    }
+    o[at] = (uint8_t)dd;
+  }
+}
+
 // K4 for back2 <= 32.  Workgroup = 256 consecutive pairs x one run of `words` 32-SNP words, so the SNP index is
-// scalar and pos / mea are scalar loads.  Every lane applies the clean form of remove_cross + getHighestId
-// (SURVEY 8a): walk the previous SNPs dd = 0..back2-1, take the first `back` that are kept for the pair, choose
-// the first strictly largest LD measure; a zero-filled row beyond the window wins over negative measures.  For a
-// pair with no missing genotype in the window this is exactly the global choose.  The emission is then a lookup in
-// tabD; no lane evaluates the 81-term polynomial.
+// scalar and pos / choose / order are scalar loads.  Every lane applies the clean form of remove_cross +
+// getHighestId: among the previous back2 SNPs take the `back` nearest that are kept for the pair and
+// choose the one with the first strictly largest LD measure; a zero-filled row beyond the window wins over negative
+// measures.  All of it on the pair's 2-bit words in registers: bit 2*dd of the reversed kept-window = SNP s-1-dd.
+// A pair with no missing genotype among its `back` nearest SNPs (99 % of lane-steps at 0.1 % missingness) takes the
+// global choose; the others walk the SNP's preference list.  The emission is then a lookup in tabD; no lane
+// evaluates the 81-term polynomial.
 __global__ void __launch_bounds__(256)
 stage_pairs_win_kernel(const uint64_t *__restrict__ Gt, int M, int Wt, const int32_t *__restrict__ pairs, int P,
                        int words, const double *__restrict__ pos, const double *__restrict__ tab1,
-                       const double *__restrict__ tabD, const double *__restrict__ mea, int useLD, int back,
+                       const double *__restrict__ tabD, const double *__restrict__ mea,
+                       const int *__restrict__ chooseG, const uint8_t *__restrict__ order, int useLD, int back,
                        int back2, EmisRec *__restrict__ rec) {
   int bpc = (P + 255) / 256;
   int c = blockIdx.x / bpc;
@@ -327,6 +352,9 @@ stage_pairs_win_kernel(const uint64_t *__restrict__ Gt, int M, int Wt, const int
   if (p >= P) return;
   const uint64_t *r1 = Gt + (size_t)pairs[2 * p] * Wt, *r2 = Gt + (size_t)pairs[2 * p + 1] * Wt;
   int w0 = c * words, w1 = min(Wt, w0 + words);
+  const uint64_t even = 0x5555555555555555ull;
+  const uint64_t wmask = back2 >= 32 ? even : (((uint64_t)1 << (2 * back2)) - 1) & even;
+  const uint64_t fastmask = (((uint64_t)1 << (2 * back)) - 1) & even;  // back <= 16
   uint64_t a_lo = 0, b_lo = 0;  // previous word of the two individuals
   int last = -1;                // last kept SNP before the current one
   if (w0 > 0) {
@@ -346,56 +374,90 @@ stage_pairs_win_kernel(const uint64_t *__restrict__ Gt, int M, int Wt, const int
     uint64_t a_hi = r1[w], b_hi = r2[w];
     uint64_t K_lo = both_present(a_lo, b_lo), K_hi = both_present(a_hi, b_hi);
     int kmax = min(32, M - w * 32);
-    for (int k = 0; k < kmax; k++) {
-      int s = w * 32 + k, q = 32 + k;
-      uint32_t g1 = (uint32_t)(a_hi >> (2 * k)) & 3u, g2 = (uint32_t)(b_hi >> (2 * k)) & 3u;
-      EmisRec r;
-      if (g1 == 0 || g2 == 0) {
-        r.t = -0.0; r.s0 = 1; r.s1 = 1; r.s2 = 1;
-      } else {
-        const double *e;
-        bool zero = false;
+    // Batches of kBatch SNPs: first all selections (register work) and the position loads, then all table loads, then
+    // all stores, so that a lane has kBatch gathers in flight instead of one memory round trip per SNP.
+    constexpr int kBatch = 8;
+    for (int k0 = 0; k0 < kmax; k0 += kBatch) {
+      const double *e[kBatch];
+      double tpos[kBatch], lpos[kBatch];
+      int state[kBatch];  // 0 dropped, 1 first kept SNP, 2 emission from e[], 3 all-zero emission
+#pragma unroll
+      for (int u = 0; u < kBatch; u++) {
+        int k = k0 + u;
+        state[u] = 0;
+        e[u] = tab1;
+        tpos[u] = 0;
+        lpos[u] = 0;
+        if (k >= kmax) continue;  // uniform
+        int s = w * 32 + k, q = 32 + k;
+        uint32_t g1 = (uint32_t)(a_hi >> (2 * k)) & 3u, g2 = (uint32_t)(b_hi >> (2 * k)) & 3u;
+        if (g1 == 0 || g2 == 0) continue;
+        e[u] = tab1 + ((size_t)s * 9 + (g1 - 1) * 3 + (g2 - 1)) * 3;
         if (last < 0) {
-          r.t = 0.0;
-          e = tab1 + ((size_t)s * 9 + (g1 - 1) * 3 + (g2 - 1)) * 3;
+          state[u] = 1;
         } else {
-          double d = pos[s] - pos[last];
-          r.t = d < 0 ? 10000000.0 : d;
-          if (!useLD) {
-            e = tab1 + ((size_t)s * 9 + (g1 - 1) * 3 + (g2 - 1)) * 3;
-          } else {
-            int nfound = 0, bestdd = -1;
-            double bv = 0;
-            int ddmax = min(back2, s);
-            for (int dd = 0; dd < ddmax; dd++) {
-              if (__all(nfound >= back)) break;
-              int q2 = q - 1 - dd;
-              bool kept = ((q2 < 32 ? K_lo : K_hi) >> (2 * (q2 & 31))) & 1u;
-              bool take = kept && nfound < back;
-              double v = mea[(size_t)dd * (M - 1) + (s - 1)];
-              bool better = take && (nfound == 0 || v > bv);
-              bv = better ? v : bv;
-              bestdd = better ? dd : bestdd;
-              nfound += take ? 1 : 0;
+          state[u] = 2;
+          tpos[u] = pos[s];
+          lpos[u] = pos[last];
+          if (useLD) {
+            // kept flags of SNPs s-32 .. s-1 (bit 2j <-> SNP s-32+j), then reversed: bit 2*dd <-> SNP s-1-dd
+            uint64_t Wk = k ? ((K_lo >> (2 * k)) | (K_hi << (64 - 2 * k))) : K_lo;
+            uint64_t sel = (__brevll(Wk) >> 1) & wmask;
+            int bestdd;
+            if ((sel & fastmask) == fastmask) {
+              bestdd = chooseG[s];
+            } else {
+              int n = __popcll(sel);
+              while (n > back) {  // keep the `back` nearest kept SNPs
+                sel &= ~((uint64_t)1 << (63 - __clzll(sel)));
+                n--;
+              }
+              bestdd = -1;
+              if (n > 0) {
+                const uint8_t *o = order + (size_t)s * back2;
+                for (int i = 0; i < back2; i++) {
+                  int dd = o[i];
+                  if (dd == 255) break;
+                  if ((sel >> (2 * dd)) & 1u) { bestdd = dd; break; }
+                }
+                // a zero-filled row beyond the kept ones wins getHighestId over a negative measure (:492)
+                if (bestdd >= 0 && n < back && 0.0 > mea[(size_t)bestdd * (M - 1) + (s - 1)]) bestdd = -1;
+              }
             }
-            if (nfound < back && 0.0 > bv) bestdd = -1;  // a zero-filled row wins getHighestId (:492)
             if (bestdd < 0) {
-              zero = true;
-              e = tab1;
+              state[u] = 3;
             } else {
               int q2 = q - 1 - bestdd;
               uint32_t h1 = win2(a_lo, a_hi, q2), h2 = win2(b_lo, b_hi, q2);
               int code = (((g1 - 1) * 3 + (g2 - 1)) * 3 + (h1 - 1)) * 3 + (h2 - 1);
-              e = tabD + (((size_t)s * back2 + bestdd) * 81 + code) * 3;
+              e[u] = tabD + (((size_t)s * back2 + bestdd) * 81 + code) * 3;
             }
           }
         }
-        r.s0 = zero ? 0.0 : e[0];
-        r.s1 = zero ? 0.0 : e[1];
-        r.s2 = zero ? 0.0 : e[2];
         last = s;
       }
-      rec[(size_t)s * P + p] = r;
+      double v[kBatch][3];
+#pragma unroll
+      for (int u = 0; u < kBatch; u++) {
+        v[u][0] = e[u][0]; v[u][1] = e[u][1]; v[u][2] = e[u][2];
+      }
+#pragma unroll
+      for (int u = 0; u < kBatch; u++) {
+        int k = k0 + u;
+        if (k >= kmax) continue;  // uniform
+        EmisRec r;
+        if (state[u] == 0) {
+          r.t = -0.0; r.s0 = 1; r.s1 = 1; r.s2 = 1;
+        } else {
+          double d = tpos[u] - lpos[u];
+          r.t = state[u] == 1 ? 0.0 : (d < 0 ? 10000000.0 : d);
+          bool zero = state[u] == 3;
+          r.s0 = zero ? 0.0 : v[u][0];
+          r.s1 = zero ? 0.0 : v[u][1];
+          r.s2 = zero ? 0.0 : v[u][2];
+        }
+        rec[(size_t)(w * 32 + k) * P + p] = r;
+      }
     }
     a_lo = a_hi;
     b_lo = b_hi;

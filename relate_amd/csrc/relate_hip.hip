@@ -68,6 +68,7 @@ struct relate_hip_ctx {
   bool winMode = false;      // stage_pairs_win_kernel + depth table (back2 <= 32)
   DBuf<double> dPos, dMaf, dMea, dPBA, dPbA, dPBa, dPba, dTab1, dTabL, dTabD;
   DBuf<int> dChoose;
+  DBuf<uint8_t> dOrder;  // per-SNP preference order of the conditioning depths (windowed staging)
   // device: staged pair block
   DBuf<EmisRec> dRec;
   DBuf<int32_t> dPairs;
@@ -139,8 +140,8 @@ int stage_block(relate_hip_t h, const int32_t *pairs, int P) {
     const int words = 2;  // 64 SNPs per thread
     unsigned grid = (unsigned)(((size_t)(h->Wt + words - 1) / words) * ((P + 255) / 256));
     hipLaunchKernelGGL(stage_pairs_win_kernel, dim3(grid), dim3(256), 0, h->stream, h->dGt.p, h->M, h->Wt, h->dPairs.p,
-                       P, words, h->dPos.p, h->dTab1.p, h->dTabD.p, h->dMea.p, h->useLD, h->o.back, h->back2,
-                       h->dRec.p);
+                       P, words, h->dPos.p, h->dTab1.p, h->dTabD.p, h->dMea.p, h->dChoose.p, h->dOrder.p, h->useLD,
+                       h->o.back, h->back2, h->dRec.p);
   } else {
     const int chunk = 64;
     long nthreads = (long)P * ((h->M + chunk - 1) / chunk);
@@ -544,7 +545,7 @@ int relate_hip_destroy(relate_hip_t h) {
   (void)hipSetDevice(h->dev);
   h->dG.release(); h->dPos.release(); h->dMaf.release(); h->dMea.release(); h->dPBA.release(); h->dPbA.release();
   h->dPBa.release(); h->dPba.release(); h->dTab1.release(); h->dTabL.release(); h->dChoose.release();
-  h->dGt.release(); h->dTabD.release();
+  h->dGt.release(); h->dTabD.release(); h->dOrder.release();
   h->dRec.release(); h->dPairs.release(); h->dLanePair.release(); h->dParams.release(); h->dOut.release();
   h->dPost.release(); h->dFwd.release(); h->dBp.release(); h->dPath.release(); h->dNsnp.release();
   h->dCm.release(); h->dAstart.release(); h->dBend.release(); h->dCe.release();
@@ -751,6 +752,10 @@ int relate_hip_precalc(relate_hip_t h, int *keep_out, int *M_out) {
       PCHK(h->dTabD.ensure((size_t)M * h->back2 * 243));
       hipLaunchKernelGGL(table_ld_depth_kernel, dim3(blocks_for((long)M * h->back2 * 81, 256)), dim3(256), 0, st,
                          h->dPBA.p, h->dPbA.p, h->dPBa.p, h->dPba.p, M, h->back2, o.epsilon, h->dTabD.p);
+      PCHK(hipGetLastError());
+      PCHK(h->dOrder.ensure((size_t)M * h->back2));
+      hipLaunchKernelGGL(ld_order_kernel, dim3(blocks_for(M, 256)), dim3(256), 0, st, h->dMea.p, M, h->back2,
+                         h->dOrder.p);
       PCHK(hipGetLastError());
     }
     h->dTabL.release();
