@@ -148,11 +148,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # Rehearsal switches for a one-GPU box (the driver's multi-GPU runs use neither): RELATE_BENCH_ONE_GPU=1 puts
+    # every rank on device 0, RELATE_BENCH_BACKEND=gloo moves the two tiny collectives to the CPU.
+    if os.environ.get("RELATE_BENCH_ONE_GPU") == "1":
+        local = 0
+    backend = os.environ.get("RELATE_BENCH_BACKEND", "nccl")
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
     import relate_amd
     from relate_amd import synth
 
@@ -200,7 +209,7 @@ def main():
         step(args.warmup + i, True)
     if dist is not None:
         # the path's only exchange: gather of per-pair results (here: one value per pair of the last block)
-        res = torch.zeros(P, dtype=torch.float64, device="cuda")
+        res = torch.zeros(P, dtype=torch.float64, device=coll_dev)
         out = [torch.zeros_like(res) for _ in range(world)]
         dist.all_gather(out, res)
     torch.cuda.synchronize()
@@ -208,7 +217,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
