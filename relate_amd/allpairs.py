@@ -1,0 +1,129 @@
+"""Multi-GPU all-pairs driver: one process per GPU (torch.distributed.run), pair blocks sharded across ranks, no
+exchange while pairs are processed, one all_gather of the per-pair estimates at the end (RCCL over xGMI with the
+"nccl" backend).  Same inputs and option file as the reference CLI / relate_amd/relateHMM_hip.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \\
+        -m relate_amd.allpairs -o options.all.pair.txt -file data/dat_small [-d keep] -out run1 [-seed N] [-no-post]
+
+Outputs: every rank writes the posterior rows of its shard to <out>.post.rank<r> (in pair order, the reference's
+.post format: concatenating the shards in rank order gives the single-process .post); rank 0 writes <out>.k (the
+reference's format) and <out>.est (pair, a, k2, k1, -logL, runs, converged, nsnp, status at full precision) for
+ALL pairs after the gather.  Posteriors are never gathered: at config 4 they are terabytes.
+
+SURVEY.md section 8(e); pair order: fast_all_pairs / joblist_fast_all_pairs (src/relateHMM.cpp:3764-3765, 3851).
+"""
+import argparse
+import os
+import time
+
+import numpy as np
+
+from . import io as rio
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser(prog="relate_amd.allpairs", prefix_chars="-")
+    ap.add_argument("-o", dest="options", required=True)
+    ap.add_argument("-file", dest="prefix")
+    ap.add_argument("-g", dest="geno")
+    ap.add_argument("-p", dest="pos")
+    ap.add_argument("-c", dest="chr")
+    ap.add_argument("-plink", dest="plink")
+    ap.add_argument("-d", dest="keep")
+    ap.add_argument("-out", dest="out", default="relate_out")
+    ap.add_argument("-seed", dest="seed", type=int, default=None)
+    ap.add_argument("-no-post", dest="no_post", action="store_true")
+    ap.add_argument("-block", dest="block", type=int, default=0, help="pairs per library call (0 = by memory)")
+    return ap.parse_args(argv)
+
+
+def load_inputs(a):
+    if a.plink:
+        front = a.plink[:-4] if a.plink.endswith((".bed", ".bim", ".fam")) else a.plink
+        return rio.load_plink(front)
+    if a.prefix:
+        front = a.prefix
+        for ext in (".geno", ".pos", ".chr"):
+            if front.endswith(ext):
+                front = front[:-len(ext)]
+        return rio.load_text(front + ".geno", front + ".pos", front + ".chr")
+    if not a.geno or not a.pos:
+        raise SystemExit("You must supply atleast a genotype file -g and a positionfile -p (or -file / -plink)")
+    return rio.load_text(a.geno, a.pos, a.chr)
+
+
+def run(a, handle_factory, dist=None, coll_device=None):
+    """Body of one rank.  handle_factory() -> object with init_globals / sgl (relate_amd.api.Relate, or a stand-in in
+    the CPU tests).  dist: an initialised torch.distributed module or None for a single process."""
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
+    opt = rio.read_options(a.options)
+    opt["seed_mode"] = 0
+    opt["seed"] = int(a.seed if a.seed is not None else time.time()) & 0xFFFFFFFF
+    geno, pos, chr_ = load_inputs(a)
+    pairs = rio.keep_list_pairs(a.keep) if a.keep else rio.all_pairs(geno.shape[0])
+    from . import api, dist as rdist
+    b, e = api.shard(len(pairs), rank, world)
+    mine = pairs[b:e]
+    H = handle_factory()
+    M = H.init_globals(geno, pos, chr_, opt)
+    k1_only = opt["fixK"] == 1 and opt["fixK_val"] == 0
+    block = a.block if a.block > 0 else max(1, min(len(mine) or 1, (1 << 30) // (24 * M)))
+    fits = []
+    post_path = "%s.post.rank%d" % (a.out, rank)
+    fh = None if a.no_post else open(post_path, "w")
+    try:
+        for b0 in range(0, len(mine), block):
+            blk = mine[b0:b0 + block]
+            res, post, _ = H.sgl(blk, want_post=not a.no_post)
+            fits.extend(res)
+            if fh is not None:
+                for n in range(len(blk)):
+                    rio.write_post_rows(fh, post[n], k1_only)
+    finally:
+        if fh is not None:
+            fh.close()
+    local = rdist.fits_to_array(fits)
+    full = rdist.gather_rows(local, len(pairs), device=coll_device) if dist is not None else local
+    if rank == 0:
+        F = {k: i for i, k in enumerate(rdist.FIT_FIELDS)}
+        with open(a.out + ".k", "w") as fk, open(a.out + ".est", "w") as fe:
+            for n in range(len(pairs)):
+                r = full[n]
+                fk.write(rio.fmt_g(r[F["k1"]]) + "\n")
+                if not k1_only:
+                    fk.write(rio.fmt_g(r[F["k2"]]) + "\n")
+                fe.write("%d\t%d\t%.17g\t%.17g\t%.17g\t%.17g\t%d\t%d\t%d\t%d\n" % (
+                    pairs[n][0], pairs[n][1], r[F["a"]], r[F["k2"]], r[F["k1"]], r[F["negloglik"]],
+                    int(r[F["timesRun"]]), int(r[F["timesConverged"]]), int(r[F["nsnp"]]), int(r[F["status"]])))
+    return full
+
+
+def main(argv=None):
+    a = parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal switches for a one-GPU box, as in bench.py
+    if os.environ.get("RELATE_BENCH_ONE_GPU") == "1":
+        local = 0
+    backend = os.environ.get("RELATE_BENCH_BACKEND", "nccl")
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("relate_amd.allpairs needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
+    from . import api
+    run(a, lambda: api.Relate(local), dist, torch.device("cuda", local) if backend == "nccl" else torch.device("cpu"))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -214,7 +214,10 @@ class Relate:
     def like(self, pairs, params):
         """params: P x E x 3 (a,k2,k1) -> P x E negative log-likelihoods (like(), src/relateHMM.cpp:1426)."""
         p, pp = self._pairs(pairs)
-        par = np.ascontiguousarray(params, dtype=np.float64).reshape(len(p), -1, 3)
+        par = np.ascontiguousarray(params, dtype=np.float64)
+        if len(p) == 0:
+            return np.zeros((0, par.shape[1] if par.ndim == 3 else 0))
+        par = par.reshape(len(p), -1, 3)
         out = np.zeros((len(p), par.shape[1]))
         self._chk(self.L.relate_hip_like(self.h, pp, len(p), par.ctypes.data_as(dp), par.shape[1],
                                          out.ctypes.data_as(dp)))

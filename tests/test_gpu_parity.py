@@ -299,3 +299,50 @@ def test_errors_are_reported_not_swallowed(gpu, prepared):
         gpu.fit([(0, 1)])
     with pytest.raises(relate_amd.RelateError):
         gpu.init_globals(g, pos, chr_, dict(opt, doPrune=1, back=0))
+
+
+@pytest.mark.parametrize("M", [2, 3, 5, 15, 16, 17, 33, 70])
+def test_tiny_marker_counts(gpu, oracle, M):
+    """Ragged ends of every loop structure: fewer SNPs than a record group (4), a posterior tile (16), a genotype
+    word (32) or two; one pair and three pairs."""
+    from relate_amd import synth
+    g, pos, chr_, _ = synth.make_dataset(8, 400, nchr=2, n_related=2, seed=5)
+    g, pos, chr_ = g[:, 100:100 + M].copy(), pos[100:100 + M].copy(), chr_[100:100 + M].copy()
+    g[0, M // 2] = 0
+    opt = dict(pc.options("options.all.pair.txt"), min=0.0)
+    p = pc.oracle_precalc(oracle, g, pos, opt)
+    try:
+        gpu.init_globals(g, pos, chr_, opt)
+    except Exception as e:  # fewer than 2 polymorphic SNPs survive the MAF filter
+        assert p["keep"].sum() < 2, e
+        return
+    assert np.array_equal(gpu.keep, p["keep"])
+    pars = np.array([(0.05, 0.2, 0.3), (0.1, 0.0, 0.4), (0.02, 0.3, 0.0)])
+    for pairs in ([(0, 1)], [(0, 1), (2, 3), (1, 7)]):
+        got = gpu.like(pairs, np.broadcast_to(pars, (len(pairs), 3, 3)).copy())
+        post, path, ns = gpu.decode(pairs, np.broadcast_to(pars[0], (len(pairs), 3)).copy(), want_path=True)
+        for n, (i, j) in enumerate(pairs):
+            st = pc.oracle_stage(oracle, p, opt, i, j)
+            keep, t, S = gpu.pair_emissions(i, j)
+            assert np.array_equal(keep, st["keep"])
+            idx = np.where(keep == 1)[0]
+            assert ns[n] == st["m"]
+            good = np.isfinite(st["S"]).all() and (st["S"] > 0).all()
+            if not good or st["m"] < 1:
+                continue
+            np.testing.assert_allclose(S[:, idx], st["S"], rtol=1e-12)
+            want = [oracle.like(d, *st["Sk"], st["t"], 0, opt["alim1"]) for d in pars]
+            np.testing.assert_allclose(got[n], want, rtol=1e-10)
+            np.testing.assert_allclose(post[n][:, idx], oracle.decode(pars[0], *st["Sk"], st["t"], 0), atol=1e-8)
+            assert (post[n][:, keep == 0] == -1).all()
+            assert np.array_equal(path[n][idx], oracle.viterbi(pars[0], *st["Sk"], st["t"], 0))
+
+
+def test_empty_pair_list_and_repeated_pairs(gpu, prepared):
+    b = pc.golden()["blocks"][0]
+    _init(gpu, prepared, b)
+    assert gpu.like(np.zeros((0, 2), dtype=np.int32), np.zeros((0, 1, 3))).shape == (0, 1)
+    pars = np.array([[(0.05, 0.2, 0.3)]] * 3)
+    v = gpu.like([(0, 1), (0, 1), (1, 0)], pars)
+    assert v[0, 0] == v[1, 0]
+    assert v[2, 0] == pytest.approx(v[0, 0], rel=1e-12)   # the pair is unordered
