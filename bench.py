@@ -100,11 +100,12 @@ def cpu_baseline(H, opt, E, want_seconds=12.0):
     gs = np.ascontiguousarray(gs[:, :Ms])
     ps, mafs = ps[:Ms].copy(), mafs[:Ms].copy()
     hap = o.hap_global(gs, opt["back2"], opt["LD"])  # pre-calc, not timed (the GPU's is not timed either)
-    par = eval_points(64, E)
+    max_pairs = 400
+    par = eval_points(max_pairs, E)
     steps = 0
     t0 = time.perf_counter()
     npairs = 0
-    for p in range(64):
+    for p in range(max_pairs):
         i, j = 2 * p + 200, 2 * p + 201
         st = o.pair_stage(gs, i, j, mafs, ps, opt["epsilon"], 1, opt["back"], opt["back2"], hap)
         Sk = o.logs(st["S"])
