@@ -134,6 +134,31 @@ void relate_rand_stream(unsigned int seed, int n, int *out);
 /* Rank r of nranks owns pairs [*begin, *end) of a list of P pairs. */
 void relate_hip_shard(int64_t P, int rank, int nranks, int64_t *begin, int64_t *end);
 
+/* ---- linkage statistic + permutation test on posterior rows (next row of the path: the reference's HMMtest) ------ */
+/* uber_main, case-control design (src/HMMtest.txt:1195-1367).  post: R x M floats, row p = the IBD0 posterior row of
+ * pair p as the .post file holds it (-1 = SNP dropped for the pair), pairs in the all-pairs order of the n_ind
+ * individuals the -D file lists, so R = n_ind (n_ind - 1) / 2.  pos: M floats or NULL (needed when infer = 1:
+ * fix_missing, :550-664).  K: R floats or NULL (NULL = row means, :941-968; isK0: use 1 - K, :674-681).
+ * cc: the -D file's values, one per individual (0 = affected, per getCaseList :717-723).
+ * Outputs (any may be NULL): stat[M] = the statistic X0 written to -f; xmax[nsim] = the -x file (observed maximum
+ * first, then one per permutation); covar[R x R] = the -c dump; post_out[R x M] = the -o dump (after inference).
+ * Results equal the reference's float arithmetic bit for bit (same summation order per output value). */
+typedef struct {
+  int nsim;        /* -Nsim, permutations incl. the observed one (default 10)        */
+  int ccAll;       /* -ccAll: 0 strict, 1 mixed pairs are cases, 2 mixed are controls */
+  int infer;       /* -infer: 1 = interpolate missing posteriors (needs pos)          */
+  int isK0;        /* K holds k0 rather than k1 (-K0)                                  */
+  float sig;       /* -sig (default 0.05)                                              */
+  unsigned seed;   /* srand(seed) before the permutations (reference: time(NULL), :1296) */
+} relate_linkage_opts;
+typedef struct {
+  double pmaxsim, psim_over_nsim, psigsim; /* the three printed summaries (:1349-1362) */
+  int n_case_pairs, n_control_pairs;
+} relate_linkage_result;
+int relate_hip_linkage(relate_hip_t h, const float *post, int R, int M, const float *pos, const float *K, const int *cc,
+                       int n_ind, const relate_linkage_opts *o, float *stat, float *xmax, float *covar, float *post_out,
+                       relate_linkage_result *res);
+
 /* ---- measurement hooks (bench.py) ----------------------------------------------------------------- */
 /* Device time in ms of the kernels launched by the last like / decode / pair_emissions-stage call,
  * measured with hipEvents on the library's stream: out = {stage_ms, like_ms, decode_fwd_ms, decode_bwd_ms}. */

@@ -97,11 +97,15 @@ static void permute_lists(int n, int n1, int seed, int *index) {
   free(in);
 }
 
-static int make_list(const int *index, int R, int which, int *list) {
-  int n = 0;
-  for (int r = 0; r < R; r++)
-    if (index[r] == which) list[n++] = r;
-  return n;
+/* generate_affectLists, :455-470: overwrites the FRONT of the two lists; their lengths stay what getCaseList made
+ * them, so when a permutation yields fewer case/control pairs than the observed lists hold (ccAll != 0 with mixed
+ * pairs) the tail keeps entries of the previous lists.  Kept: it is what the reference computes. */
+static void fill_lists(const int *index, int R, int *la, int *ln) {
+  int a = 0, n = 0;
+  for (int r = 0; r < R; r++) {
+    if (index[r] == 1) la[a++] = r;
+    else if (index[r] == 2) ln[n++] = r;
+  }
 }
 
 static float list_mean(const float *K, const int *list, int n) { /* get_mean, :831-840 */
@@ -135,9 +139,8 @@ static float pooled_bottom(int na, int nn, float varU1, float varU0) { /* :1279 
   return (float)sqrt(u);
 }
 
-static void statistic(const float *post, int R, int M, const float *K, const float *cov, const int *index, int missing,
-                      int *la, int *ln, float *U1, float *U0, float *X) {
-  int na = make_list(index, R, 1, la), nn = make_list(index, R, 2, ln);
+static void statistic(const float *post, int R, int M, const float *K, const float *cov, int missing, const int *la,
+                      int na, const int *ln, int nn, float *U1, float *U0, float *X) {
   float mn1 = list_mean(K, la, na), mn0 = list_mean(K, ln, nn);
   col_means(post, M, la, na, missing, U1);
   col_means(post, M, ln, nn, missing, U0);
@@ -188,16 +191,20 @@ int orc_linkage(float *post, int R, int M, const float *pos, const float *Kin, i
   int *psim = (int *)calloc(M, sizeof(int));
   int n1, n0;
   case_lists(cc, n_ind, ccAll, index, &n1, &n0);
-  summary[3] = make_list(index, R, 1, la);
-  summary[4] = make_list(index, R, 2, ln);
-  statistic(post, R, M, K, cov, index, missing, la, ln, U1, U0, stat);
+  int na = 0, nn = 0;
+  for (int r = 0; r < R; r++) { na += index[r] == 1; nn += index[r] == 2; }
+  summary[3] = na;
+  summary[4] = nn;
+  fill_lists(index, R, la, ln);
+  statistic(post, R, M, K, cov, missing, la, na, ln, nn, U1, U0, stat);
   srand(seed);
   float mx = stat[0];
   for (int s = 1; s < M; s++) if (stat[s] > mx) mx = stat[s];
   xmax[0] = mx;
   for (int i = 1; i < nsim; i++) {
     permute_lists(n0 + n1, n1, rand(), index);
-    statistic(post, R, M, K, cov, index, missing, la, ln, U1, U0, Xi);
+    fill_lists(index, R, la, ln);
+    statistic(post, R, M, K, cov, missing, la, na, ln, nn, U1, U0, Xi);
     mx = Xi[0];
     for (int s = 0; s < M; s++) {
       if (Xi[s] >= stat[s]) psim[s]++;

@@ -32,6 +32,16 @@ class RelateOpts(C.Structure):
                 ("seed_mode", C.c_int), ("seed", C.c_uint)]
 
 
+class LinkageOpts(C.Structure):
+    _fields_ = [("nsim", C.c_int), ("ccAll", C.c_int), ("infer", C.c_int), ("isK0", C.c_int), ("sig", C.c_float),
+                ("seed", C.c_uint)]
+
+
+class LinkageResult(C.Structure):
+    _fields_ = [("pmaxsim", C.c_double), ("psim_over_nsim", C.c_double), ("psigsim", C.c_double),
+                ("n_case_pairs", C.c_int), ("n_control_pairs", C.c_int)]
+
+
 class RelateFit(C.Structure):
     _fields_ = [("a", C.c_double), ("k2", C.c_double), ("k1", C.c_double), ("k0", C.c_double),
                 ("negloglik", C.c_double), ("uLike", C.c_double), ("poLike", C.c_double), ("timesRun", C.c_int),
@@ -91,6 +101,9 @@ def load_library():
     L.relate_hip_shard.restype = None
     L.relate_hip_last_timings.argtypes = [vp, dp]
     L.relate_hip_last_chunks.argtypes = [vp, ip, ip]
+    fpt = C.POINTER(C.c_float)
+    L.relate_hip_linkage.argtypes = [vp, fpt, C.c_int, C.c_int, fpt, fpt, ip, C.c_int, C.POINTER(LinkageOpts), fpt, fpt,
+                                     fpt, fpt, C.POINTER(LinkageResult)]
     L.relate_hip_bench_like.argtypes = [vp, i32p, C.c_int, dp, C.c_int, C.c_int, dp]
     L.relate_hip_bench_decode.argtypes = [vp, i32p, C.c_int, dp, C.c_int, dp, dp]
     _lib = L
@@ -258,6 +271,28 @@ class Relate:
                                               None if path is None else path.ctypes.data_as(i8p)))
         res = [{f: getattr(o, f) for f, _ in RelateFit._fields_} for o in out]
         return res, post, path
+
+    # -- linkage (HMMtest) -------------------------------------------------------------------------
+    def linkage(self, post, cc, pos=None, K=None, isK0=0, nsim=10, ccAll=0, sig=0.05, infer=1, seed=1,
+                want_cov=False, want_post=False):
+        """uber_main of the reference's HMMtest (src/HMMtest.txt:1195-1367), case-control design."""
+        fpt = C.POINTER(C.c_float)
+        p = np.ascontiguousarray(post, dtype=np.float32)
+        R, M = p.shape
+        c = np.ascontiguousarray(cc, dtype=np.int32)
+        ps = None if pos is None else np.ascontiguousarray(pos, dtype=np.float32)
+        k = None if K is None else np.ascontiguousarray(K, dtype=np.float32)
+        o = LinkageOpts(nsim, ccAll, infer, isK0, sig, seed)
+        stat = np.zeros(M, dtype=np.float32)
+        xmax = np.zeros(nsim, dtype=np.float32)
+        cov = np.zeros((R, R), dtype=np.float32) if want_cov else None
+        pout = np.zeros((R, M), dtype=np.float32) if want_post else None
+        res = LinkageResult()
+        f = lambda a: None if a is None else a.ctypes.data_as(fpt)  # noqa: E731
+        self._chk(self.L.relate_hip_linkage(self.h, f(p), R, M, f(ps), f(k), c.ctypes.data_as(ip), len(c), C.byref(o),
+                                            f(stat), f(xmax), f(cov), f(pout), C.byref(res)))
+        return dict(stat=stat, xmax=xmax, cov=cov, post=pout, pmaxsim=res.pmaxsim, psim_over_nsim=res.psim_over_nsim,
+                    psigsim=res.psigsim, n_case_pairs=res.n_case_pairs, n_control_pairs=res.n_control_pairs)
 
     # -- measurement -------------------------------------------------------------------------------
     def timings(self):

@@ -17,6 +17,7 @@
 #include "fit.hpp"
 #include "kernels_emis.hpp"
 #include "kernels_hmm.hpp"
+#include "kernels_linkage.hpp"
 #include "kernels_precalc.hpp"
 
 using namespace relate;
@@ -1011,3 +1012,204 @@ int relate_hip_bench_decode(relate_hip_t h, const int32_t *pairs, int P, const d
 }
 
 }  // extern "C"
+
+// ---- linkage (HMMtest) ---------------------------------------------------------------------------------------
+namespace {
+
+double lk_lcg01(int *seed) {  // d_uniform_01, src/HMMtest.txt:1063-1072
+  int k = *seed / 127773;
+  *seed = 16807 * (*seed - k * 127773) - k * 2836;
+  if (*seed < 0) *seed = *seed + 2147483647;
+  return (double)(*seed) * 4.656612875E-10;
+}
+
+// getCaseList (:693-829): code per pair row: 1 case pair, 2 control pair, 0 unused
+void lk_case_codes(const int *cc, int n, int ccAll, uint8_t *code, int *n1, int *n0) {
+  std::vector<char> aff(n);
+  int na = 0;
+  for (int i = 0; i < n; i++) { aff[i] = cc[i] ? 0 : 1; na += aff[i]; }
+  *n1 = na;
+  *n0 = n - na;
+  size_t row = 0;
+  for (int i = 0; i < n - 1; i++)
+    for (int j = i + 1; j < n; j++, row++) {
+      int v;
+      if (aff[i] && aff[j]) v = 1;
+      else if (aff[j]) v = -1;  // the reference's second branch (:785): excluded whatever ccAll says
+      else if (!aff[i] && !aff[j]) v = 2;
+      else v = 0;
+      if (v == 0 && ccAll == 2) v = 2;
+      else if (v == 0 && ccAll == 1) v = 1;
+      code[row] = v > 0 ? (uint8_t)v : 0;
+    }
+}
+
+// permutate_dFileList (:1113-1143) with perm_uniform (:1094-1109)
+void lk_perm_codes(int n, int n1, int seed, uint8_t *code) {
+  std::vector<int> p(n);
+  std::vector<char> in(n, 0);
+  for (int i = 1; i <= n; i++) p[i - 1] = i;
+  for (int i = 1; i <= n; i++) {
+    int j = i + (int)(lk_lcg01(&seed) * (double)(n + 1 - i));
+    if (j < i) j = i;
+    if (n < j) j = n;
+    std::swap(p[i - 1], p[j - 1]);
+  }
+  for (int i = 0; i < n1; i++) in[p[i] - 1] = 1;
+  size_t row = 0;
+  for (int i = 0; i < n - 1; i++)
+    for (int j = i + 1; j < n; j++, row++) code[row] = (in[i] && in[j]) ? 1 : ((!in[i] && !in[j]) ? 2 : 0);
+}
+
+}  // namespace
+
+extern "C" int relate_hip_linkage(relate_hip_t h, const float *post, int R, int M, const float *pos, const float *K,
+                                  const int *cc, int n_ind, const relate_linkage_opts *o, float *stat, float *xmax,
+                                  float *covar, float *post_out, relate_linkage_result *res) {
+  if (!h) return fail(nullptr, RELATE_E_ARG, "null handle");
+  if (!post || !cc || !o || R < 1 || M < 2 || n_ind < 2 || o->nsim < 1) return fail(h, RELATE_E_ARG, "bad arguments");
+  if ((long)n_ind * (n_ind - 1) / 2 != R)
+    return fail(h, RELATE_E_ARG, "the posterior file must hold one row per pair of the individuals in the -D file (" +
+                                     std::to_string((long)n_ind * (n_ind - 1) / 2) + " rows, got " + std::to_string(R) + ")");
+  if (o->infer == 1 && !pos) return fail(h, RELATE_E_ARG, "Position file required for removing missing");
+  if (set_device(h)) return RELATE_E_HIP;
+  hipStream_t st = h->stream;
+  const int nsim = o->nsim;
+  DBuf<float> dP, dPos, dK, dCov, dU1, dU0, dScal, dX0, dXmax;
+  DBuf<int> dPsim;
+  auto cleanup = [&]() {
+    dP.release(); dPos.release(); dK.release(); dCov.release(); dU1.release(); dU0.release(); dScal.release();
+    dX0.release(); dXmax.release(); dPsim.release();
+  };
+#define LCHK(expr)                                                                              \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) {                                                                     \
+      cleanup();                                                                                \
+      return fail(h, e_ == hipErrorOutOfMemory ? RELATE_E_NOMEM : RELATE_E_HIP,                 \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                           \
+    }                                                                                           \
+  } while (0)
+  LCHK(dP.ensure((size_t)R * M));
+  LCHK(hipMemcpyAsync(dP.p, post, sizeof(float) * (size_t)R * M, hipMemcpyHostToDevice, st));
+  int missing = 1;
+  if (o->infer == 1) {
+    LCHK(dPos.ensure(M));
+    LCHK(hipMemcpyAsync(dPos.p, pos, sizeof(float) * M, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(lk_fix_missing_kernel, dim3(blocks_for(R, 64)), dim3(64), 0, st, dP.p, R, M, dPos.p);
+    LCHK(hipGetLastError());
+    missing = 0;
+  }
+  LCHK(dK.ensure(R));
+  if (K) {
+    std::vector<float> k(R);
+    for (int r = 0; r < R; r++) k[r] = o->isK0 ? 1 - K[r] : K[r];
+    LCHK(hipMemcpyAsync(dK.p, k.data(), sizeof(float) * R, hipMemcpyHostToDevice, st));
+    LCHK(hipStreamSynchronize(st));
+  } else {
+    hipLaunchKernelGGL(lk_row_mean_kernel, dim3(blocks_for(R, 64)), dim3(64), 0, st, dP.p, R, M, missing, dK.p);
+    LCHK(hipGetLastError());
+  }
+  LCHK(dCov.ensure((size_t)R * R));
+  {
+    unsigned g = (unsigned)((R + kCovT - 1) / kCovT);
+    hipLaunchKernelGGL(lk_covar_kernel, dim3(g, g), dim3(256), 0, st, dP.p, dK.p, R, M, missing, dCov.p);
+    LCHK(hipGetLastError());
+  }
+  // Case lists and permutations (host: integer bookkeeping on the glibc rand() / LCG streams).  The reference keeps
+  // two list arrays whose LENGTHS are fixed by getCaseList; every permutation overwrites their front
+  // (generate_affectLists, :455-470).  With ccAll != 0 the observed lists also hold the mixed pairs, a permutation
+  // yields only C(n1,2) / C(n0,2) pairs, and the tail keeps entries of the previous lists.  Kept, list by list.
+  std::vector<uint8_t> code(R);
+  int n1 = 0, n0 = 0;
+  lk_case_codes(cc, n_ind, o->ccAll, code.data(), &n1, &n0);
+  int LA = 0, LN = 0;
+  for (int r = 0; r < R; r++) { LA += code[r] == 1; LN += code[r] == 2; }
+  if (LA < 1 || LN < 1) { cleanup(); return fail(h, RELATE_E_ARG, "the case/control file leaves no case pairs or no control pairs"); }
+  std::vector<int> la_all((size_t)nsim * LA), ln_all((size_t)nsim * LN);
+  {
+    std::vector<int> la(LA), ln(LN);
+    auto fill = [&]() {
+      int a = 0, n = 0;
+      for (int r = 0; r < R; r++) {
+        if (code[r] == 1) la[a++] = r;
+        else if (code[r] == 2) ln[n++] = r;
+      }
+    };
+    GlibcRand rng(o->seed);  // srand(time(NULL)) (:1296); one rand() per permutation (:1116)
+    for (int i = 0; i < nsim; i++) {
+      if (i > 0) lk_perm_codes(n0 + n1, n1, rng.next(), code.data());
+      fill();
+      std::copy(la.begin(), la.end(), la_all.begin() + (size_t)i * LA);
+      std::copy(ln.begin(), ln.end(), ln_all.begin() + (size_t)i * LN);
+    }
+  }
+  DBuf<int> dLa, dLn;
+  auto cleanup2 = [&]() { dLa.release(); dLn.release(); cleanup(); };
+#define L2CHK(expr)                                                                             \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) {                                                                     \
+      cleanup2();                                                                               \
+      return fail(h, e_ == hipErrorOutOfMemory ? RELATE_E_NOMEM : RELATE_E_HIP,                 \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                           \
+    }                                                                                           \
+  } while (0)
+  L2CHK(dLa.ensure(la_all.size()));
+  L2CHK(dLn.ensure(ln_all.size()));
+  L2CHK(hipMemcpyAsync(dLa.p, la_all.data(), sizeof(int) * la_all.size(), hipMemcpyHostToDevice, st));
+  L2CHK(hipMemcpyAsync(dLn.p, ln_all.data(), sizeof(int) * ln_all.size(), hipMemcpyHostToDevice, st));
+  L2CHK(dX0.ensure(M));
+  L2CHK(dXmax.ensure(nsim));
+  L2CHK(dPsim.ensure(M));
+  L2CHK(hipMemsetAsync(dPsim.p, 0, sizeof(int) * M, st));
+  const int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsim, ((size_t)256 << 20) / ((size_t)M * 8)));
+  L2CHK(dU1.ensure((size_t)batch * M));
+  L2CHK(dU0.ensure((size_t)batch * M));
+  L2CHK(dScal.ensure((size_t)3 * batch));
+  for (int b0 = 0; b0 < nsim; b0 += batch) {
+    int nb = std::min(batch, nsim - b0);
+    const int *a = dLa.p + (size_t)b0 * LA, *n = dLn.p + (size_t)b0 * LN;
+    hipLaunchKernelGGL(lk_col_means_kernel, dim3(blocks_for(M, 256), nb), dim3(256), 0, st, dP.p, M, a, LA, n, LN, missing,
+                       dU1.p, dU0.p);
+    L2CHK(hipGetLastError());
+    hipLaunchKernelGGL(lk_perm_scalars_kernel, dim3(blocks_for(nb, 64)), dim3(64), 0, st, dK.p, dCov.p, R, a, LA, n, LN, nb,
+                       dScal.p);
+    L2CHK(hipGetLastError());
+    hipLaunchKernelGGL(lk_statistic_kernel, dim3(blocks_for(M, 256), nb), dim3(256), 0, st, dU1.p, dU0.p, dScal.p, M);
+    L2CHK(hipGetLastError());
+    if (b0 == 0) L2CHK(hipMemcpyAsync(dX0.p, dU1.p, sizeof(float) * M, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(lk_perm_reduce_kernel, dim3(nb), dim3(256), 0, st, dU1.p, dX0.p, M, nb, b0 == 0 ? 1 : 0,
+                       dXmax.p + b0, dPsim.p);
+    L2CHK(hipGetLastError());
+  }
+  const int n_case = LA, n_ctrl = LN;
+  std::vector<float> hx(nsim);
+  std::vector<int> hps(M);
+  L2CHK(hipMemcpyAsync(hx.data(), dXmax.p, sizeof(float) * nsim, hipMemcpyDeviceToHost, st));
+  L2CHK(hipMemcpyAsync(hps.data(), dPsim.p, sizeof(int) * M, hipMemcpyDeviceToHost, st));
+  if (stat) L2CHK(hipMemcpyAsync(stat, dX0.p, sizeof(float) * M, hipMemcpyDeviceToHost, st));
+  if (covar) L2CHK(hipMemcpyAsync(covar, dCov.p, sizeof(float) * (size_t)R * R, hipMemcpyDeviceToHost, st));
+  if (post_out) L2CHK(hipMemcpyAsync(post_out, dP.p, sizeof(float) * (size_t)R * M, hipMemcpyDeviceToHost, st));
+  L2CHK(hipStreamSynchronize(st));
+  cleanup2();
+#undef LCHK
+#undef L2CHK
+  if (xmax) std::memcpy(xmax, hx.data(), sizeof(float) * nsim);
+  if (res) {  // the printed summaries (:1349-1362): counting, the reference's float accumulations, its sort
+    float pmax = 1;
+    for (int i = 1; i < nsim; i++)
+      if (hx[0] <= hx[i]) pmax++;
+    res->pmaxsim = pmax / nsim;
+    float ps = 0;
+    for (int s = 0; s < M; s++) ps += hps[s];
+    res->psim_over_nsim = ps / (float)nsim;
+    std::vector<float> sorted(hx);
+    std::sort(sorted.begin(), sorted.end());
+    int at = (int)std::round((double)((1 - o->sig) * nsim)) - 1;
+    res->psigsim = (at >= 0 && at < nsim) ? sorted[at] : NAN;
+    res->n_case_pairs = n_case;
+    res->n_control_pairs = n_ctrl;
+  }
+  return RELATE_OK;
+}

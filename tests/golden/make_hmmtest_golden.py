@@ -16,12 +16,16 @@ POST = os.path.join(HERE, "cli", "c5_out.post")
 POS = os.path.join(HERE, "cli", "c5_stripped.pos")
 KF = os.path.join(HERE, "cli", "c5_out.k")
 CC = os.path.join(HERE, "data", "dat_small.cc")
+MIX = os.path.join(HERE, "hmmtest", "mixed.cc")  # this repo's own file: statuses interleaved, so mixed pairs exist
 
 CASES = {
     "default": ["-P", POST, "-D", CC, "-infer", "1", "-p", POS, "-Nsim", "200"],
     "ccall2": ["-P", POST, "-D", CC, "-infer", "1", "-p", POS, "-Nsim", "100", "-ccAll", "2"],
     "missing": ["-P", POST, "-D", CC, "-infer", "0", "-Nsim", "100"],
     "kfile": ["-P", POST, "-D", CC, "-infer", "1", "-p", POS, "-Nsim", "100", "-K", KF],
+    "mixed0": ["-P", POST, "-D", MIX, "-infer", "1", "-p", POS, "-Nsim", "100"],
+    "mixed1": ["-P", POST, "-D", MIX, "-infer", "1", "-p", POS, "-Nsim", "100", "-ccAll", "1"],
+    "mixed2": ["-P", POST, "-D", MIX, "-infer", "0", "-Nsim", "100", "-ccAll", "2"],
 }
 
 out = {"seed": 4242, "cases": {}}

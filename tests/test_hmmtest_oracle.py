@@ -7,7 +7,7 @@ import pytest
 import hmmtestcheck as hc
 
 
-@pytest.mark.parametrize("name", ["default", "ccall2", "missing", "kfile"])
+@pytest.mark.parametrize("name", ["default", "ccall2", "missing", "kfile", "mixed0", "mixed1", "mixed2"])
 def test_oracle_reproduces_reference_output(name):
     G = hc.golden()
     case = G["cases"][name]
