@@ -2,8 +2,9 @@
 // Replaces error/errorNoLD/emission2_new/errorLD/LDemission_new/LD2_new and the per-pair table
 // re-indexing remove_cross/getHighestId (src/relateHMM.cpp:2776-2975, 850-971, 481-497).  gfx950 only.
 //
-// Emission records live SNP-major in HBM: rec[s * P + p] = {t, S_ibd0, S_ibd1, S_ibd2} (32 B) for pair p
-// of the staged block.  A SNP dropped for that pair (a missing genotype) is {-0.0, 1, 1, 1}: an identity step
+// Emission records live SNP-major in HBM: rec[s * RP + p] = {t, S_ibd0, S_ibd1, S_ibd2} (32 B) for pair p
+// of the staged block; RP >= P is the row pitch in records, chosen by the host so that consecutive SNP rows do not lie
+// a power of two apart.  A SNP dropped for that pair (a missing genotype) is {-0.0, 1, 1, 1}: an identity step
 // for the recursions, flagged by the sign bit of t; the pair's first kept SNP has t = +0.0 (the reference's
 // t[0] = 0).  Lanes of a wave hold consecutive pairs, so every step reads/writes 64 x 32 B = 2 KiB contiguous.
 #pragma once
@@ -188,7 +189,7 @@ __global__ void stage_pairs_kernel(const uint64_t *__restrict__ G, int M, int W,
                                    const double *__restrict__ mea, const double *__restrict__ pBA,
                                    const double *__restrict__ pbA, const double *__restrict__ pBa,
                                    const double *__restrict__ pba, int useLD, int back, int back2, double eps,
-                                   EmisRec *__restrict__ rec) {
+                                   EmisRec *__restrict__ rec, int RP) {
   long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   int nchunk = (M + chunk - 1) / chunk;
   if (tid >= (long)P * nchunk) return;
@@ -258,7 +259,7 @@ __global__ void stage_pairs_kernel(const uint64_t *__restrict__ G, int M, int W,
       last = s;
       if (run < back) run++;
     }
-    rec[(size_t)s * P + p] = r;
+    rec[(size_t)s * RP + p] = r;
   }
 }
 
@@ -345,12 +346,21 @@ stage_pairs_win_kernel(const uint64_t *__restrict__ Gt, int M, int Wt, const int
                        int words, const double *__restrict__ pos, const double *__restrict__ tab1,
                        const double *__restrict__ tabD, const double *__restrict__ mea,
                        const int *__restrict__ chooseG, const uint8_t *__restrict__ order, int useLD, int back,
-                       int back2, EmisRec *__restrict__ rec) {
+                       int back2, EmisRec *__restrict__ rec, int RP) {
+  // Records leave through LDS: a lane's 32-byte record as two 16-byte stores at a 32-byte lane stride would touch
+  // sixteen 128-byte lines per store instruction and fill half of each; instead every wave parks its 64 records in
+  // its own 2 KiB of LDS and reads them back as 128 consecutive 16-byte pieces, so that each store instruction
+  // writes 1 KiB of whole lines.
+  __shared__ __attribute__((aligned(16))) EmisRec xch[4][64];
   int bpc = (P + 255) / 256;
   int c = blockIdx.x / bpc;
   int p = (blockIdx.x % bpc) * 256 + threadIdx.x;
-  if (p >= P) return;
-  const uint64_t *r1 = Gt + (size_t)pairs[2 * p] * Wt, *r2 = Gt + (size_t)pairs[2 * p + 1] * Wt;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int pw0 = p - lane;  // first pair of this wave
+  if (pw0 >= P) return;      // whole wave beyond the block
+  const int pc = p < P ? p : P - 1;  // dead lanes of a live wave shadow the last pair: they take part in the exchange
+  const bool liveA = pw0 + (lane >> 1) < P, liveB = pw0 + 32 + (lane >> 1) < P;
+  const uint64_t *r1 = Gt + (size_t)pairs[2 * pc] * Wt, *r2 = Gt + (size_t)pairs[2 * pc + 1] * Wt;
   int w0 = c * words, w1 = min(Wt, w0 + words);
   const uint64_t even = 0x5555555555555555ull;
   const uint64_t wmask = back2 >= 32 ? even : (((uint64_t)1 << (2 * back2)) - 1) & even;
@@ -456,7 +466,14 @@ stage_pairs_win_kernel(const uint64_t *__restrict__ Gt, int M, int Wt, const int
           r.s1 = zero ? 0.0 : v[u][1];
           r.s2 = zero ? 0.0 : v[u][2];
         }
-        rec[(size_t)(w * 32 + k) * P + p] = r;
+        xch[wv][lane] = r;
+        __builtin_amdgcn_wave_barrier();
+        const double2 *q = (const double2 *)&xch[wv][0];
+        double2 pa = q[lane], pb = q[64 + lane];
+        __builtin_amdgcn_wave_barrier();
+        double2 *o = (double2 *)(rec + (size_t)(w * 32 + k) * RP + pw0);
+        if (liveA) o[lane] = pa;
+        if (liveB) o[64 + lane] = pb;
       }
     }
     a_lo = a_hi;

@@ -6,16 +6,18 @@
 // Numerics.  The reference walks the SNPs in log space (3 exp + 6 log per step).  Here the recursion runs in the
 // linear domain and is renormalised by exact powers of two every 8 steps; the exponent is accumulated as an
 // integer and one log is taken at the end.  The two exponentials per step (e^{-a t}, e^{-a k1 t}; a is per lane,
-// t per SNP) are inherent; they are evaluated as expm1 with a wave-uniform choice of polynomial degree, because
-// the transition matrix is affine in (e1 - 1, e2 - 1) with NO constant term off the diagonal:
-//     T01 = T21 = -k1 m1              m1 = expm1(-a t), m2 = expm1(-a k1 t)
-//     T02 = k2/(k1-1) d               d  = m2 - k1 m1
-//     T20 = k0/(k1-1) d               T10 = T01 k0/k1,  T12 = T01 k2/k1,   diagonal = 1 - row sum
+// t per SNP) are inherent; they enter only through expm1, because the transition matrix is affine in
+// (e1 - 1, e2 - 1) with NO constant term off the diagonal:
+//     T01 = T21 = u = -k1 m1          m1 = expm1(-a t), m2 = expm1(-a k1 t)
+//     T02 = k2 w,  T20 = k0 w         w  = (m2 - k1 m1)/(k1 - 1)
+//     T10 = u k0/k1,  T12 = u k2/k1,  diagonal = 1 - row sum
 // which is the reference's T (src/relateHMM.cpp:1452-1489) with its constant terms cancelled analytically
 // (k0 + k1 + k2 = 1); the reference's own rounding noise in T02/T20 (which its fix_underflow clamps below 1e-15,
-// :542-547) does not arise.  like() is reproduced to <= 1e-13 relative (tests/test_gpu_parity.py).
+// :542-547) does not arise.  For |a t| < 2^-7 (the normal case at SNP-chip density) u and w are two short
+// polynomials in -a t with per-lane coefficients (LaneC); a forward step is then 13 + 14 FP64 instructions per
+// vector.  like() is reproduced to <= 1e-13 relative (tests/test_gpu_parity.py).
 //
-// Records.  rec[s * P + p] = {t, S_ibd0, S_ibd1, S_ibd2} (32 B).  A SNP dropped for the pair is stored as
+// Records.  rec[s * RP + p] = {t, S_ibd0, S_ibd1, S_ibd2} (32 B; RP = row pitch >= P, kernels_emis.hpp).  A SNP dropped for the pair is stored as
 // {-0.0, 1, 1, 1}: T(0) = I exactly, so the step is the identity and no lane ever branches on it; the sign bit
 // of t is the "dropped" flag for the kernels that must know (posterior = -1, Viterbi).  The pair's first kept SNP
 // has t = +0.0 (the reference's t[0] = 0): the start vector k passes through T(0) = I and picks up S.
@@ -24,7 +26,7 @@
 // axis is cut into C chunks: the per-step matrices A_s = T(t_s) diag(S_s) compose associatively,
 // chunk_matrix_kernel forms every chunk's product (three row vectors with their own power-of-two exponents) and a
 // short combine kernel folds the C products per lane.  The exponentials and T are shared by the three rows, so a
-// chunked step costs ~1.5x a plain one.  A workgroup is 256 lanes of ONE chunk, so loop bounds are scalar.
+// chunked step costs ~2x a plain one.  A workgroup is 256 lanes of ONE chunk, so loop bounds are scalar.
 //
 // Memory.  Every lane streams its column of records, 4 records (128 B) per group, double-buffered in registers.
 #pragma once
@@ -39,11 +41,12 @@ static constexpr int kGroup = 4;     // records per load group (two groups in fl
 static constexpr double kLn2 = 0.6931471805599453094;
 
 // ---- expm1 for x <= 0 ------------------------------------------------------------------------------------
-__device__ inline double em_tiny(double x) {  // |x| < 2^-9: x + x^2 (1/2 + x/6 + x^2/24 + x^3/120), rel. err < 5e-17
-  double p = __builtin_fma(x, 1.0 / 120, 1.0 / 24);
+__device__ inline double em_tiny(double x, double xx) {  // |x| < 2^-7: x + x^2 (1/2 + ... + x^4/720), rel. err < 6e-17
+  double p = __builtin_fma(x, 1.0 / 720, 1.0 / 120);
+  p = __builtin_fma(x, p, 1.0 / 24);
   p = __builtin_fma(x, p, 1.0 / 6);
   p = __builtin_fma(x, p, 0.5);
-  return __builtin_fma(x * x, p, x);
+  return __builtin_fma(xx, p, x);
 }
 __device__ inline double em_small(double x) {  // |x| < 2^-4: Taylor through x^10/10!
   double p = 1.0 / 3628800;
@@ -80,22 +83,26 @@ __device__ inline double em_general(double x) {  // any x <= 0: exp by range red
   return (x > -0.0625) ? em_small(x) : g;  // also routes NaN to the propagating branch
 }
 
-// expm1 at a given tier: 0 = |x| < 2^-9, 1 = |x| < 2^-4, 2 = any x <= 0.  The tier is chosen per wave and per
-// group of records (lanes of a wave sit on the same SNPs, so t is uniform up to per-pair dropped SNPs and |x|
-// differs only through a, k1): straight-line code for the whole group, no per-step branch.
-template <int TIER>
-__device__ inline double em(double x) {
-  return TIER == 0 ? em_tiny(x) : (TIER == 1 ? em_small(x) : em_general(x));
-}
+// Tiers of the per-step exponentials: 0 = |a t| < 2^-7, 1 = |a t| < 2^-4, 2 = any t.  The tier is chosen per wave and
+// per group of records (lanes of a wave sit on the same SNPs, so t is uniform up to per-pair dropped SNPs and |a t|
+// differs only through a): straight-line code for the whole group, no per-step branch.
 
 // ---- per-lane constants, hoisted out of the SNP loop (src/relateHMM.cpp:1440-1490) -------------------------
+// With m1 = expm1(-a t), m2 = expm1(-a k1 t), x = -a t:
+//     u = T01 = T21 = -k1 m1,     T10 = u k0/k1,   T12 = u k2/k1
+//     w = (m2 - k1 m1)/(k1 - 1) = sum_{j>=2} g_j x^j,   g_j = k1 (1 + k1 + ... + k1^(j-2)) / j!
+//     T02 = k2 w,   T20 = k0 w
+// The series form of w has no cancellation and no division; it is used in tier 0 (terms through x^6, absolute
+// truncation error < 3e-18) and the closed form in the other tiers.  k1 == 1 forces k0 = k2 = 0, so T02 = T20 = 0 as
+// the reference sets them (:1461-1489); k1 == 0 gives u = w = 0.
 struct LaneC {
-  double na, nak1;  // -a, -a*k1
-  double nk1;       // -k1
-  double c02, c20;  // k2/(k1-1), k0/(k1-1); both 0 when k1 == 1 (the reference zeroes T02, T20 there)
-  double r10, r12;  // k0/k1, k2/k1; both 1 when k1 == 0
+  double na, nak1;      // -a, -a*k1
+  double nk1;           // -k1
   double k0, k1, k2;
-  double tlim0, tlim1;  // t below which |a t| < 2^-9 / 2^-4
+  double r10, r12, rs;  // k0/k1, k2/k1 (both 1 when k1 == 0), and their sum
+  double ikm1;          // 1/(k1-1); 0 when k1 == 1
+  double g2, g3, g4, g5, g6;
+  double tlim0, tlim1;  // t below which |a t| < 2^-7 / 2^-4
 };
 
 __device__ inline LaneC make_lane(double a, double k2, double k1, double k0) {
@@ -104,38 +111,65 @@ __device__ inline LaneC make_lane(double a, double k2, double k1, double k0) {
   C.nak1 = -a * k1;
   C.nk1 = -k1;
   C.k0 = k0; C.k1 = k1; C.k2 = k2;
-  C.tlim0 = 0x1p-9 / a;
+  C.tlim0 = 0x1p-7 / a;
   C.tlim1 = 0x1p-4 / a;
-  double km1 = k1 - 1;
-  bool one = (k1 == 1);
-  C.c02 = one ? 0.0 : k2 / km1;
-  C.c20 = one ? 0.0 : k0 / km1;
+  C.ikm1 = (k1 == 1) ? 0.0 : 1.0 / (k1 - 1);
   if (k1 == 0) { C.r10 = 1; C.r12 = 1; } else { C.r10 = k0 / k1; C.r12 = k2 / k1; }
+  C.rs = C.r10 + C.r12;
+  double s = 1.0;               // 1 + k1 + ... + k1^(j-2)
+  C.g2 = k1 * s * (1.0 / 2);
+  s = __builtin_fma(s, k1, 1.0);
+  C.g3 = k1 * s * (1.0 / 6);
+  s = __builtin_fma(s, k1, 1.0);
+  C.g4 = k1 * s * (1.0 / 24);
+  s = __builtin_fma(s, k1, 1.0);
+  C.g5 = k1 * s * (1.0 / 120);
+  s = __builtin_fma(s, k1, 1.0);
+  C.g6 = k1 * s * (1.0 / 720);
   return C;
 }
 
-// the off-diagonal transition probabilities for distance t (T21 = T01)
-struct OffDiag {
-  double t01, t02, t10, t12, t20;
+// m1 = expm1(-a t) alone (double-recombination model)
+template <int TIER>
+__device__ inline double m1_at(const LaneC &C, double t) {
+  double x = C.na * t;
+  return TIER == 0 ? em_tiny(x, x * x) : (TIER == 1 ? em_small(x) : em_general(x));
+}
+
+// the two numbers that carry the distance t into the transition matrix
+struct Trans {
+  double u, w;
 };
 template <int TIER>
-__device__ inline OffDiag offdiag_at(const LaneC &C, double t) {
-  double m1 = em<TIER>(C.na * t), m2 = em<TIER>(C.nak1 * t);
-  OffDiag T;
-  T.t01 = C.nk1 * m1;
-  double d = __builtin_fma(C.nk1, m1, m2);
-  T.t02 = C.c02 * d;
-  T.t20 = C.c20 * d;
-  T.t10 = T.t01 * C.r10;
-  T.t12 = T.t01 * C.r12;
+__device__ inline Trans trans_at(const LaneC &C, double t) {
+  Trans T;
+  double x = C.na * t;
+  if (TIER == 0) {
+    double xx = x * x;
+    T.u = C.nk1 * em_tiny(x, xx);
+    double q = __builtin_fma(x, C.g6, C.g5);
+    q = __builtin_fma(x, q, C.g4);
+    q = __builtin_fma(x, q, C.g3);
+    q = __builtin_fma(x, q, C.g2);
+    T.w = xx * q;
+  } else {
+    double x2 = C.nak1 * t;
+    double m1 = TIER == 1 ? em_small(x) : em_general(x);
+    double m2 = TIER == 1 ? em_small(x2) : em_general(x2);
+    T.u = C.nk1 * m1;
+    T.w = __builtin_fma(C.nk1, m1, m2) * C.ikm1;
+  }
   return T;
 }
 
 // v <- (v T) o S for NV row vectors sharing one T (forward step); DR = double recombination (dbl_recom, :501-507)
+//   new0 = f0 + u (f1 r10 - f0) + w (f2 k0 - f0 k2)
+//   new1 = f1 + u (f0 + f2 - f1 (r10 + r12))
+//   new2 = f2 + u (f1 r12 - f2) - w (f2 k0 - f0 k2)
 template <int NV, bool DR, int TIER>
 __device__ inline void fwd_step(const LaneC &C, const EmisRec &r, double (&x)[NV][3]) {
   if (DR) {
-    double m1 = em<TIER>(C.na * r.t);  // T_xy = (1 - e1) k_y + [x == y] e1
+    double m1 = m1_at<TIER>(C, r.t);  // T_xy = (1 - e1) k_y + [x == y] e1
 #pragma unroll
     for (int v = 0; v < NV; v++) {
       double F = (x[v][0] + x[v][1]) + x[v][2];
@@ -147,53 +181,41 @@ __device__ inline void fwd_step(const LaneC &C, const EmisRec &r, double (&x)[NV
     }
     return;
   }
-  OffDiag T = offdiag_at<TIER>(C, r.t);
-  double a0 = T.t01 + T.t02, a1 = T.t10 + T.t12, a2 = T.t01 + T.t20;
-  if (NV > 1) {
-    // several vectors share T and S: fold the emission into the columns once (11 shared multiplies/adds), then
-    // 9 operations per vector instead of 15
-    double c00 = (1.0 - a0) * r.s0, c10 = T.t10 * r.s0, c20 = T.t20 * r.s0;
-    double c01 = T.t01 * r.s1, c11 = (1.0 - a1) * r.s1;
-    double c02 = T.t02 * r.s2, c12 = T.t12 * r.s2, c22 = (1.0 - a2) * r.s2;
-#pragma unroll
-    for (int v = 0; v < NV; v++) {
-      double f0 = x[v][0], f1 = x[v][1], f2 = x[v][2];
-      x[v][0] = __builtin_fma(f2, c20, __builtin_fma(f1, c10, f0 * c00));
-      x[v][1] = __builtin_fma(f0 + f2, c01, f1 * c11);
-      x[v][2] = __builtin_fma(f2, c22, __builtin_fma(f1, c12, f0 * c02));
-    }
-    return;
-  }
+  Trans T = trans_at<TIER>(C, r.t);
 #pragma unroll
   for (int v = 0; v < NV; v++) {
     double f0 = x[v][0], f1 = x[v][1], f2 = x[v][2];
-    double u0 = __builtin_fma(f2, T.t20, __builtin_fma(f1, T.t10, __builtin_fma(-f0, a0, f0)));
-    double u1 = __builtin_fma(f0 + f2, T.t01, __builtin_fma(-f1, a1, f1));
-    double u2 = __builtin_fma(f1, T.t12, __builtin_fma(f0, T.t02, __builtin_fma(-f2, a2, f2)));
+    double A = __builtin_fma(f1, C.r10, -f0);
+    double B = __builtin_fma(f2, C.k0, -(f0 * C.k2));
+    double Cc = __builtin_fma(-f1, C.rs, f0 + f2);
+    double D = __builtin_fma(f1, C.r12, -f2);
+    double u0 = __builtin_fma(T.w, B, __builtin_fma(T.u, A, f0));
+    double u1 = __builtin_fma(T.u, Cc, f1);
+    double u2 = __builtin_fma(-T.w, B, __builtin_fma(T.u, D, f2));
     x[v][0] = u0 * r.s0;
     x[v][1] = u1 * r.s1;
     x[v][2] = u2 * r.s2;
   }
 }
 
-// b <- T (S o b) (backward step through the record of the LATER SNP)
+// b <- T (S o b) (backward step through the record of the LATER SNP):  n_x = q_x + sum_{y != x} T_xy (q_y - q_x)
 template <bool DR, int TIER>
 __device__ inline void bwd_step(const LaneC &C, const EmisRec &r, double &b0, double &b1, double &b2) {
   double q0 = r.s0 * b0, q1 = r.s1 * b1, q2 = r.s2 * b2;
   if (DR) {
-    double m1 = em<TIER>(C.na * r.t);
+    double m1 = m1_at<TIER>(C, r.t);
     double G = __builtin_fma(C.k2, q2, __builtin_fma(C.k1, q1, C.k0 * q0));  // sum_y k_y q_y
     b0 = __builtin_fma(m1, q0 - G, q0);
     b1 = __builtin_fma(m1, q1 - G, q1);
     b2 = __builtin_fma(m1, q2 - G, q2);
     return;
   }
-  OffDiag T = offdiag_at<TIER>(C, r.t);
-  // n_x = q_x + sum_{y != x} T_xy (q_y - q_x)
+  Trans T = trans_at<TIER>(C, r.t);
   double d10 = q1 - q0, d20 = q2 - q0, d21 = q2 - q1;
-  b0 = __builtin_fma(T.t02, d20, __builtin_fma(T.t01, d10, q0));
-  b1 = __builtin_fma(T.t12, d21, __builtin_fma(-T.t10, d10, q1));
-  b2 = __builtin_fma(-T.t20, d20, __builtin_fma(-T.t01, d21, q2));
+  double z = __builtin_fma(-C.r10, d10, C.r12 * d21);
+  b0 = __builtin_fma(T.w, C.k2 * d20, __builtin_fma(T.u, d10, q0));
+  b1 = __builtin_fma(T.u, z, q1);
+  b2 = __builtin_fma(-T.w, C.k0 * d20, __builtin_fma(-T.u, d21, q2));
 }
 
 // exact rescale of a 3-vector by a power of two; returns the exponent removed (0 for an all-zero vector)
@@ -215,17 +237,14 @@ __device__ inline bool lane_params(const double *__restrict__ params, int l, dou
 
 __device__ inline bool rec_dropped(const EmisRec &r) { return __builtin_signbit(r.t); }
 
-// wave-uniform tier of a group of N records: 0 if every lane has |a t| < 2^-9 for all of them, 1 if < 2^-4, else 2
+// wave-uniform tier of a group of N records: 0 if every lane has |a t| < 2^-7 for all of them, 1 if < 2^-4, else 2
 template <int N>
 __device__ inline int group_tier(const LaneC &C, const EmisRec (&R)[N]) {
-  bool t0 = true, t1 = true;
+  double tmax = R[0].t;
 #pragma unroll
-  for (int u = 0; u < N; u++) {
-    t0 = t0 && (R[u].t < C.tlim0);
-    t1 = t1 && (R[u].t < C.tlim1);
-  }
-  if (__all(t0)) return 0;
-  if (__all(t1)) return 1;
+  for (int u = 1; u < N; u++) tmax = __builtin_fmax(tmax, R[u].t);
+  if (__builtin_amdgcn_ballot_w64(!(tmax < C.tlim0)) == 0) return 0;
+  if (__builtin_amdgcn_ballot_w64(!(tmax < C.tlim1)) == 0) return 1;
   return 2;
 }
 
@@ -271,14 +290,21 @@ __device__ inline void stream_records(const EmisRec *__restrict__ col, size_t st
   for (; s < se; s++) on_tail(col[(size_t)s * stride], s);
 }
 
-static constexpr int kNbuf = 2;  // measured: 4 costs occupancy (216 vs 152 VGPRs) and gains nothing at 5 TB/s
+// groups in flight per lane, per kernel (register budget: 32 VGPRs per group)
+#ifndef RELATE_NBUF_LIKE
+#define RELATE_NBUF_LIKE 2
+#endif
+#ifndef RELATE_NBUF_CHUNK
+#define RELATE_NBUF_CHUNK 2
+#endif
+static constexpr int kNbuf = 2;  // decode sweeps; measured: 4 costs occupancy (216 vs 152 VGPRs) and gains nothing at 5 TB/s
 
 // forward recursion over rows [sb, se) for NV vectors
-template <int NV, bool DR>
-__device__ inline void sweep(const EmisRec *__restrict__ rec, int P, int lp, int sb, int se, int M, const LaneC &C,
+template <int NV, bool DR, int NBUF>
+__device__ inline void sweep(const EmisRec *__restrict__ rec, int RP, int lp, int sb, int se, int M, const LaneC &C,
                              double (&x)[NV][3], int (&ex)[NV]) {
-  stream_records<kNbuf>(
-      rec + lp, (size_t)P, sb, se, M,
+  stream_records<NBUF>(
+      rec + lp, (size_t)RP, sb, se, M,
       [&](const EmisRec(&R)[kGroup], int s) {
         fwd_group<NV, DR>(C, R, x);
         if (s & kGroup) {  // every second group: 8 steps between renormalisations
@@ -294,7 +320,7 @@ __device__ inline void sweep(const EmisRec *__restrict__ rec, int P, int lp, int
 // K5, one sweep.  out[l] = -log-likelihood, SYS_MAX for a rejected point, NaN/inf if the recursion broke down.
 template <bool DR>
 __global__ void __launch_bounds__(256)
-like_kernel(const EmisRec *__restrict__ rec, int M, int P, const int32_t *__restrict__ lane_pair,
+like_kernel(const EmisRec *__restrict__ rec, int M, int RP, const int32_t *__restrict__ lane_pair,
             const double *__restrict__ params, int nlanes, double alim1, double *__restrict__ out) {
   int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= nlanes) return;
@@ -303,7 +329,7 @@ like_kernel(const EmisRec *__restrict__ rec, int M, int P, const int32_t *__rest
   LaneC C = make_lane(a, k2, k1, k0);
   double x[1][3] = {{k0, k1, k2}};
   int ex[1] = {0};
-  sweep<1, DR>(rec, P, lane_pair[l], 0, M, M, C, x, ex);
+  sweep<1, DR, RELATE_NBUF_LIKE>(rec, RP, lane_pair[l], 0, M, M, C, x, ex);
   double tot = (x[0][0] + x[0][1]) + x[0][2];
   out[l] = -(log(tot) + (double)ex[0] * kLn2);
 }
@@ -319,7 +345,7 @@ struct ChunkOut {
 
 template <bool DR>
 __global__ void __launch_bounds__(256)
-chunk_matrix_kernel(const EmisRec *__restrict__ rec, int M, int P, const int32_t *__restrict__ lane_pair,
+chunk_matrix_kernel(const EmisRec *__restrict__ rec, int M, int RP, const int32_t *__restrict__ lane_pair,
                     const double *__restrict__ params, int nlanes, int nlp, int nchunk, int chunk_len, double alim1,
                     int reject, ChunkOut O) {
   int bpc = nlp / 256;  // workgroups per chunk
@@ -332,7 +358,7 @@ chunk_matrix_kernel(const EmisRec *__restrict__ rec, int M, int P, const int32_t
   int sb = c * chunk_len, se = min(M, sb + chunk_len);
   double x[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
   int ex[3] = {0, 0, 0};
-  sweep<3, DR>(rec, P, lane_pair ? lane_pair[l] : l, sb, se, M, C, x, ex);
+  sweep<3, DR, RELATE_NBUF_CHUNK>(rec, RP, lane_pair ? lane_pair[l] : l, sb, se, M, C, x, ex);
   size_t n = (size_t)nlp * nchunk, at = (size_t)c * nlp + l;
 #pragma unroll
   for (int i = 0; i < 3; i++) {
@@ -461,7 +487,7 @@ __device__ inline void put_ckpt(double *__restrict__ q, size_t plane, double (&x
 // ckpt[(r * nhalf + s / 4) * P + p]: vector entering the half tile that starts at SNP s.
 template <bool DR>
 __global__ void __launch_bounds__(256)
-decode_fwd_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *__restrict__ params, int nlp,
+decode_fwd_kernel(const EmisRec *__restrict__ rec, int M, int P, int RP, const double *__restrict__ params, int nlp,
                   int chunk_len, const double *__restrict__ astart, double *__restrict__ ckpt, int *__restrict__ nsnp) {
   int bpc = nlp / 256;
   int c = blockIdx.x / bpc;
@@ -481,7 +507,7 @@ decode_fwd_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *_
   double *kcol = ckpt + p;
   int m = 0;
   stream_records<kNbuf>(
-      rec + p, stride, sb, se, M,
+      rec + p, (size_t)RP, sb, se, M,
       [&](const EmisRec(&R)[kGroup], int s) {
         put_ckpt(kcol + (size_t)(s / kGroup) * stride, plane, x);
         dec_fwd_dispatch<DR>(C, R, x, m);
@@ -532,7 +558,7 @@ __device__ inline void dec_bwd_half(const LaneC &C, const EmisRec (&R)[kGroup], 
 
 template <bool DR>
 __global__ void __launch_bounds__(kBwdThreads)
-decode_bwd_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *__restrict__ params, int nlp,
+decode_bwd_kernel(const EmisRec *__restrict__ rec, int M, int P, int RP, const double *__restrict__ params, int nlp,
                   int chunk_len, const double *__restrict__ bend, const double *__restrict__ ckpt,
                   double *__restrict__ post) {
   __shared__ double tile[3][kBwdThreads][kTilePad];
@@ -560,7 +586,7 @@ decode_bwd_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *_
       if (hb >= te) continue;  // uniform: ragged last tile
       EmisRec R[kGroup];
 #pragma unroll
-      for (int u = 0; u < kGroup; u++) R[u] = rec[(size_t)min(hb + u, te - 1) * stride + pc];
+      for (int u = 0; u < kGroup; u++) R[u] = rec[(size_t)min(hb + u, te - 1) * RP + pc];
       const double *f = ckpt + (size_t)(hb / kGroup) * stride + pc;
       double f0 = f[0], f1 = f[plane], f2 = f[2 * plane];
       int tier = group_tier<kGroup>(C, R);
@@ -641,7 +667,7 @@ __device__ inline void ref_trans_at(const RefTrans &C, double t, double (&T)[3][
 }
 
 __global__ void __launch_bounds__(256)
-viterbi_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *__restrict__ params, int double_recom,
+viterbi_kernel(const EmisRec *__restrict__ rec, int M, int P, int RP, const double *__restrict__ params, int double_recom,
                uint8_t *__restrict__ bp, int8_t *__restrict__ path) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
@@ -651,7 +677,7 @@ viterbi_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *__re
   double v0 = 0, v1 = 0, v2 = 0;
   bool started = false;
   for (int s = 0; s < M; s++) {
-    EmisRec r = rec[(size_t)s * P + p];
+    EmisRec r = rec[(size_t)s * RP + p];
     if (rec_dropped(r)) continue;
     double l0 = log(r.s0), l1 = log(r.s1), l2 = log(r.s2);
     if (!started) {
@@ -678,7 +704,7 @@ viterbi_kernel(const EmisRec *__restrict__ rec, int M, int P, const double *__re
   int8_t *out = path + (size_t)p * M;
   int cur = started ? vwhich3(v0, v1, v2) : -1;
   for (int s = M - 1; s >= 0; s--) {
-    if (rec_dropped(rec[(size_t)s * P + p])) { out[s] = -1; continue; }
+    if (rec_dropped(rec[(size_t)s * RP + p])) { out[s] = -1; continue; }
     out[s] = (int8_t)cur;
     cur = (bp[(size_t)s * P + p] >> (2 * cur)) & 3;
   }

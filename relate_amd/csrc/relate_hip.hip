@@ -74,6 +74,7 @@ struct relate_hip_ctx {
   DBuf<EmisRec> dRec;
   DBuf<int32_t> dPairs;
   std::vector<int32_t> staged;  // pairs of the block currently in dRec (2 ints per pair)
+  int recPitch = 0;             // row pitch of dRec in records (>= pairs of the staged block)
   // device: work
   DBuf<int32_t> dLanePair;
   DBuf<double> dParams, dOut, dPost;
@@ -85,6 +86,7 @@ struct relate_hip_ctx {
   DBuf<int> dCe;
   double timings[4] = {0, 0, 0, 0};
   int last_chunks[2] = {1, 1};  // SNP-axis chunks of the last like / decode launch
+  long slots_like = 2048, slots_decode = 6144;  // resident waves of the chunked sweeps (set at create)
 };
 
 namespace {
@@ -104,6 +106,16 @@ int fail(relate_hip_t h, int code, const std::string &msg) {
   } while (0)
 
 inline unsigned blocks_for(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+// Row pitch of the staged record block: P rounded up to 64 records (2 KiB), then made an odd number of 2 KiB units,
+// so that consecutive SNP rows never lie a power of two apart (HBM channel camping of the strided sweeps).  Small
+// blocks stay dense.
+inline int rec_pitch(int P) {
+  if (P < 256) return P;
+  int u = (P + 63) / 64;
+  if ((u & 1) == 0) u++;
+  return u * 64;
+}
 
 int set_device(relate_hip_t h) {
   HIPCHK(h, hipSetDevice(h->dev));
@@ -133,7 +145,8 @@ int stage_block(relate_hip_t h, const int32_t *pairs, int P) {
       return fail(h, RELATE_E_ARG, "pair index out of range (the data set has " + std::to_string(h->N) + " individuals)");
   }
   h->staged.clear();
-  HIPCHK(h, h->dRec.ensure((size_t)h->M * P));
+  h->recPitch = rec_pitch(P);
+  HIPCHK(h, h->dRec.ensure((size_t)h->M * h->recPitch));
   HIPCHK(h, h->dPairs.ensure((size_t)2 * P));
   HIPCHK(h, hipMemcpyAsync(h->dPairs.p, pairs, sizeof(int32_t) * 2 * P, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
@@ -142,14 +155,14 @@ int stage_block(relate_hip_t h, const int32_t *pairs, int P) {
     unsigned grid = (unsigned)(((size_t)(h->Wt + words - 1) / words) * ((P + 255) / 256));
     hipLaunchKernelGGL(stage_pairs_win_kernel, dim3(grid), dim3(256), 0, h->stream, h->dGt.p, h->M, h->Wt, h->dPairs.p,
                        P, words, h->dPos.p, h->dTab1.p, h->dTabD.p, h->dMea.p, h->dChoose.p, h->dOrder.p, h->useLD,
-                       h->o.back, h->back2, h->dRec.p);
+                       h->o.back, h->back2, h->dRec.p, h->recPitch);
   } else {
     const int chunk = 64;
     long nthreads = (long)P * ((h->M + chunk - 1) / chunk);
     hipLaunchKernelGGL(stage_pairs_kernel, dim3(blocks_for(nthreads, 256)), dim3(256), 0, h->stream, h->dG.p, h->M,
                        h->W, h->dPairs.p, P, chunk, h->dPos.p, h->dTab1.p, h->dTabL.p, h->dChoose.p, h->dMea.p,
                        h->dPBA.p, h->dPbA.p, h->dPBa.p, h->dPba.p, h->useLD, h->o.back, h->back2, h->o.epsilon,
-                       h->dRec.p);
+                       h->dRec.p, h->recPitch);
   }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
@@ -162,18 +175,21 @@ int stage_block(relate_hip_t h, const int32_t *pairs, int P) {
 }
 
 // SNP-axis chunking.  A sweep lane carries a serial chain of M steps; below about two waves per SIMD the
-// machine idles, so the SNP axis is cut until there are enough threads -- but a chunked step costs ~1.5x a plain
-// one, so a launch that already has >= ~1.5 waves per SIMD stays a single sweep.  When cutting, the likelihood
-// aims for ~12 waves per SIMD: its kernels hold 2 waves per SIMD at a time, and with only a few waves per SIMD in
-// total the last, partly filled round costs up to a third of the run time.  Decode aims for 4 (its combine kernel
-// walks the chunks serially per pair and its sweeps are HBM-bound, not latency-bound).  Chunks are multiples of 16 SNPs (the posterior tiles
-// of decode_bwd_kernel) and at least 512 SNPs long.
-void pick_chunks(int M, long lanes, int waves_per_simd, int *nchunk, int *chunk_len) {
+// machine idles, so the SNP axis is cut until there are enough threads -- but a chunked step costs ~2x a plain
+// one, so a launch that already has >= ~1.5 waves per SIMD stays a single sweep.  When cutting, the number of
+// chunks is the largest one whose waves still fit `rounds` full turns of the `slots` waves the kernels of the launch
+// can hold at once (hipOccupancy at create time; for decode the least common multiple over its three kernels): one
+// chunk more would add a turn that runs nearly empty (a seventh of the run time at 6 turns).  The likelihood uses
+// 12 turns; decode one turn of the common multiple (its combine kernel walks the chunks serially per pair and its
+// sweeps are HBM-bound, not latency-bound).  Chunks are multiples of 16 SNPs (the posterior tiles of
+// decode_bwd_kernel) and at least 512 SNPs long.
+void pick_chunks(int M, long lanes, int wg_threads, long slots, int rounds, int *nchunk, int *chunk_len) {
   const long simd_lanes = 256L * 4 * 64;  // one wave on every SIMD
   long c = 1;
   if (lanes < simd_lanes * 3 / 2) {
-    const long target = simd_lanes * waves_per_simd;
-    c = lanes > 0 ? (target + lanes - 1) / lanes : 1;
+    long wg = (lanes + wg_threads - 1) / wg_threads;
+    long waves_per_chunk = wg * ((wg_threads + 63) / 64);
+    c = (slots * rounds) / std::max(1L, waves_per_chunk);
   }
   long cmax = std::max(1, M / 512);
   if (c > cmax) c = cmax;
@@ -182,6 +198,20 @@ void pick_chunks(int M, long lanes, int waves_per_simd, int *nchunk, int *chunk_
   len = (len + 15) / 16 * 16;
   *chunk_len = len;
   *nchunk = (M + len - 1) / len;
+}
+
+long lcm(long a, long b) {
+  long x = a, y = b;
+  while (y) { long t = x % y; x = y; y = t; }
+  return a / x * b;
+}
+
+// waves a kernel can hold on the whole device at once
+template <class K>
+long wave_slots(K kernel, int block, int ncu) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, 0) != hipSuccess || nb < 1) nb = 1;
+  return (long)nb * ((block + 63) / 64) * ncu;
 }
 
 inline int pad256(int n) { return (n + 255) / 256 * 256; }
@@ -197,15 +227,15 @@ int ensure_chunk_buffers(relate_hip_t h, size_t n, ChunkOut *O) {
 // K5 launches on lanes already uploaded to dLanePair/dParams; result in dOut (device)
 int launch_like(relate_hip_t h, int P, int nl) {
   int nchunk, clen;
-  pick_chunks(h->M, nl, 12, &nchunk, &clen);
+  pick_chunks(h->M, nl, 256, h->slots_like, 12, &nchunk, &clen);
   h->last_chunks[0] = nchunk;
   const bool dr = h->o.double_recom != 0;
   if (nchunk == 1) {
     if (dr)
-      hipLaunchKernelGGL(like_kernel<true>, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, h->dRec.p, h->M, P,
+      hipLaunchKernelGGL(like_kernel<true>, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch,
                          h->dLanePair.p, h->dParams.p, nl, h->o.alim[1], h->dOut.p);
     else
-      hipLaunchKernelGGL(like_kernel<false>, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, h->dRec.p, h->M, P,
+      hipLaunchKernelGGL(like_kernel<false>, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch,
                          h->dLanePair.p, h->dParams.p, nl, h->o.alim[1], h->dOut.p);
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -217,10 +247,10 @@ int launch_like(relate_hip_t h, int P, int nl) {
   if (rc) return rc;
   dim3 grid((unsigned)((size_t)(nlp / 256) * nchunk));
   if (dr)
-    hipLaunchKernelGGL(chunk_matrix_kernel<true>, grid, dim3(256), 0, h->stream, h->dRec.p, h->M, P, h->dLanePair.p,
+    hipLaunchKernelGGL(chunk_matrix_kernel<true>, grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch, h->dLanePair.p,
                        h->dParams.p, nl, nlp, nchunk, clen, h->o.alim[1], 1, O);
   else
-    hipLaunchKernelGGL(chunk_matrix_kernel<false>, grid, dim3(256), 0, h->stream, h->dRec.p, h->M, P, h->dLanePair.p,
+    hipLaunchKernelGGL(chunk_matrix_kernel<false>, grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch, h->dLanePair.p,
                        h->dParams.p, nl, nlp, nchunk, clen, h->o.alim[1], 1, O);
   HIPCHK(h, hipGetLastError());
   hipLaunchKernelGGL(like_combine_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, O, h->dParams.p, nl, nlp,
@@ -428,7 +458,7 @@ int fit_block(relate_hip_t h, int P, const int32_t *pairs, long pair_base, const
 int launch_decode(relate_hip_t h, int P) {
   const int M = h->M;
   int nchunk, clen;
-  pick_chunks(M, P, 4, &nchunk, &clen);
+  pick_chunks(M, P, 256, h->slots_decode, 1, &nchunk, &clen);
   h->last_chunks[1] = nchunk;
   const bool dr = h->o.double_recom != 0;
   const int nlp = pad256(P);
@@ -444,10 +474,10 @@ int launch_decode(relate_hip_t h, int P) {
     HIPCHK(h, h->dAstart.ensure((size_t)3 * n));
     HIPCHK(h, h->dBend.ensure((size_t)3 * n));
     if (dr)
-      hipLaunchKernelGGL(chunk_matrix_kernel<true>, grid, dim3(256), 0, h->stream, h->dRec.p, M, P,
+      hipLaunchKernelGGL(chunk_matrix_kernel<true>, grid, dim3(256), 0, h->stream, h->dRec.p, M, h->recPitch,
                          (const int32_t *)nullptr, h->dParams.p, P, nlp, nchunk, clen, h->o.alim[1], 0, O);
     else
-      hipLaunchKernelGGL(chunk_matrix_kernel<false>, grid, dim3(256), 0, h->stream, h->dRec.p, M, P,
+      hipLaunchKernelGGL(chunk_matrix_kernel<false>, grid, dim3(256), 0, h->stream, h->dRec.p, M, h->recPitch,
                          (const int32_t *)nullptr, h->dParams.p, P, nlp, nchunk, clen, h->o.alim[1], 0, O);
     HIPCHK(h, hipGetLastError());
     hipLaunchKernelGGL(decode_combine_kernel, dim3(blocks_for(P, 256)), dim3(256), 0, h->stream, O, h->dParams.p, P,
@@ -457,19 +487,19 @@ int launch_decode(relate_hip_t h, int P) {
     bend = h->dBend.p;
   }
   if (dr)
-    hipLaunchKernelGGL(decode_fwd_kernel<true>, grid, dim3(256), 0, h->stream, h->dRec.p, M, P, h->dParams.p, nlp, clen,
+    hipLaunchKernelGGL(decode_fwd_kernel<true>, grid, dim3(256), 0, h->stream, h->dRec.p, M, P, h->recPitch, h->dParams.p, nlp, clen,
                        astart, h->dFwd.p, h->dNsnp.p);
   else
-    hipLaunchKernelGGL(decode_fwd_kernel<false>, grid, dim3(256), 0, h->stream, h->dRec.p, M, P, h->dParams.p, nlp,
+    hipLaunchKernelGGL(decode_fwd_kernel<false>, grid, dim3(256), 0, h->stream, h->dRec.p, M, P, h->recPitch, h->dParams.p, nlp,
                        clen, astart, h->dFwd.p, h->dNsnp.p);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
   dim3 bgrid((unsigned)((size_t)((P + kBwdThreads - 1) / kBwdThreads) * nchunk));
   if (dr)
-    hipLaunchKernelGGL(decode_bwd_kernel<true>, bgrid, dim3(kBwdThreads), 0, h->stream, h->dRec.p, M, P, h->dParams.p,
+    hipLaunchKernelGGL(decode_bwd_kernel<true>, bgrid, dim3(kBwdThreads), 0, h->stream, h->dRec.p, M, P, h->recPitch, h->dParams.p,
                        nlp, clen, bend, h->dFwd.p, h->dPost.p);
   else
-    hipLaunchKernelGGL(decode_bwd_kernel<false>, bgrid, dim3(kBwdThreads), 0, h->stream, h->dRec.p, M, P,
+    hipLaunchKernelGGL(decode_bwd_kernel<false>, bgrid, dim3(kBwdThreads), 0, h->stream, h->dRec.p, M, P, h->recPitch,
                        h->dParams.p, nlp, clen, bend, h->dFwd.p, h->dPost.p);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
@@ -503,7 +533,7 @@ int decode_block(relate_hip_t h, int P, const double *params, double *post, int8
   if (path) {
     HIPCHK(h, h->dBp.ensure((size_t)M * P));
     HIPCHK(h, h->dPath.ensure((size_t)M * P));
-    hipLaunchKernelGGL(viterbi_kernel, dim3(blocks_for(P, 256)), dim3(256), 0, h->stream, h->dRec.p, M, P,
+    hipLaunchKernelGGL(viterbi_kernel, dim3(blocks_for(P, 256)), dim3(256), 0, h->stream, h->dRec.p, M, P, h->recPitch,
                        h->dParams.p, h->o.double_recom, h->dBp.p, h->dPath.p);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(path, h->dPath.p, (size_t)M * P, hipMemcpyDeviceToHost, h->stream));
@@ -537,6 +567,18 @@ int relate_hip_create(relate_hip_t *out, int device_id) {
       delete h;
       return fail(nullptr, RELATE_E_HIP, "hipEventCreate failed");
     }
+  {
+    hipDeviceProp_t prop;
+    int ncu = 256;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+      ncu = prop.multiProcessorCount;
+    long sc = wave_slots(chunk_matrix_kernel<false>, 256, ncu);
+    long sf = wave_slots(decode_fwd_kernel<false>, 256, ncu);
+    long sb = wave_slots(decode_bwd_kernel<false>, kBwdThreads, ncu);
+    h->slots_like = sc;
+    // decode launches (P / 64) waves per chunk in each of its three sweeps
+    h->slots_decode = lcm(lcm(sc, sf), sb);
+  }
   *out = h;
   return RELATE_OK;
 }
