@@ -80,6 +80,14 @@ const char *relate_hip_last_error(relate_hip_t h); /* h may be NULL: error of a 
  * sorted by (chr,pos) as mysort leaves them (src/asort.cpp:37-88). */
 int relate_hip_load(relate_hip_t h, const uint8_t *geno, int N, int M_raw, const double *pos, const int *chr,
                     const relate_opts *opts);
+/* PLINK ingestion without the reference's int matrix: replaces bed_to_iMatrix + extractOK(keeplist) + mysort on the
+ * genotype matrix (src/filereader_and_conversions.cpp:483-564, src/runRelate.cpp:363-381).  bed: the SNP-major .bed
+ * payload after its 3-byte header (0x6C 0x1B 0x01), n_snp_bed rows of ceil(N/4) bytes.  cols[M_raw]: the .bed rows to
+ * analyse, in analysis order -- the caller applies doBimFile's autosome filter (:634-640) and the (chr,pos) sort
+ * (src/asort.cpp:37-88) to the short per-SNP vectors and passes the resulting order; pos (already / 1e6, src/conf.h) and
+ * chr are in that order.  The 2-bit fields are recoded on the GPU by relate_hip_precalc ({1,0,2,3} then 1 <-> 3). */
+int relate_hip_load_bed(relate_hip_t h, const uint8_t *bed, int N, int n_snp_bed, const int *cols, int M_raw,
+                        const double *pos, const int *chr, const relate_opts *opts);
 /* calcMaf + maf_stripper + [getMea + pruning3] + global MAF + snp_pair_range(back2) + emission tables.
  * keep_out (M_raw ints, may be NULL) = pre_calc_used_list; *M_out = SNPs kept. */
 int relate_hip_precalc(relate_hip_t h, int *keep_out, int *M_out);

@@ -87,6 +87,7 @@ def load_library():
     L.relate_hip_last_error.restype = C.c_char_p
     L.relate_hip_last_error.argtypes = [vp]
     L.relate_hip_load.argtypes = [vp, u8p, C.c_int, C.c_int, dp, ip, C.POINTER(RelateOpts)]
+    L.relate_hip_load_bed.argtypes = [vp, u8p, C.c_int, C.c_int, ip, C.c_int, dp, ip, C.POINTER(RelateOpts)]
     L.relate_hip_precalc.argtypes = [vp, ip, ip]
     L.relate_hip_get_stripped.argtypes = [vp, u8p, dp, dp]
     L.relate_hip_get_hap.argtypes = [vp, dp, dp, dp, dp, dp, ip]
@@ -186,6 +187,29 @@ class Relate:
         self.N, self.Mraw = g.shape
         self._chk(self.L.relate_hip_load(self.h, g.ctypes.data_as(u8p), g.shape[0], g.shape[1], p.ctypes.data_as(dp),
                                          None if c is None else c.ctypes.data_as(ip), C.byref(s)))
+        keep = np.zeros(self.Mraw, dtype=np.int32)
+        M = C.c_int(0)
+        self._chk(self.L.relate_hip_precalc(self.h, keep.ctypes.data_as(ip), C.byref(M)))
+        self.M = M.value
+        self.keep = keep
+        return self.M
+
+    def init_globals_bed(self, bed_payload, n_ind, cols, pos, chr_, opts):
+        """init_globals on a PLINK .bed payload (SNP-major, header stripped): the 2-bit fields are recoded on the GPU,
+        no byte-per-genotype matrix is formed.  cols/pos/chr_: relate_amd.io.read_plink_raw()."""
+        b = np.ascontiguousarray(bed_payload, dtype=np.uint8)
+        cl = np.ascontiguousarray(cols, dtype=np.int32)
+        p = np.ascontiguousarray(pos, dtype=np.float64)
+        c = None if chr_ is None else np.ascontiguousarray(chr_, dtype=np.int32)
+        bps = (n_ind + 3) // 4
+        if b.size % bps:
+            raise ValueError(".bed payload is not a whole number of %d-byte SNP rows" % bps)
+        self.opts = dict(default_opts(), **{k: v for k, v in opts.items()})
+        s = make_opts(self.opts)
+        self.N, self.Mraw = n_ind, len(cl)
+        self._chk(self.L.relate_hip_load_bed(self.h, b.ctypes.data_as(u8p), n_ind, b.size // bps, cl.ctypes.data_as(ip),
+                                             len(cl), p.ctypes.data_as(dp),
+                                             None if c is None else c.ctypes.data_as(ip), C.byref(s)))
         keep = np.zeros(self.Mraw, dtype=np.int32)
         M = C.c_int(0)
         self._chk(self.L.relate_hip_precalc(self.h, keep.ctypes.data_as(ip), C.byref(M)))

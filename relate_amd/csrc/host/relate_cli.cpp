@@ -87,6 +87,9 @@ double token_to_double(const std::string &t) {
 struct DataSet {
   int N = 0, M = 0;
   std::vector<uint8_t> geno;  // N x M
+  std::vector<uint8_t> bed;   // SNP-major PLINK payload (then geno stays empty and cols names its rows)
+  std::vector<int> cols;
+  int bed_rows = 0;
   std::vector<double> pos;
   std::vector<int> chr;
 };
@@ -223,9 +226,20 @@ void read_plink(const std::string &bed, const std::string &bim, const std::strin
     if (chr_all[s] != 0 && chr_all[s] < 23) keep.push_back(s);
   d->N = n_ind;
   d->M = (int)keep.size();
-  d->geno.assign((size_t)d->N * d->M, 0);
   d->pos.resize(d->M);
   d->chr.resize(d->M);
+  std::printf("\t-> Plink file contains %d autosomale SNP's\n", d->M);
+  if (snp_major) {  // the payload goes to the GPU as it is (relate_hip_load_bed); only the short vectors are handled here
+    for (int c = 0; c < d->M; c++) {
+      d->pos[c] = pos_all[keep[c]] / 1000000;  // PLINK_POS_SCALING, src/conf.h:8
+      d->chr[c] = chr_all[keep[c]];
+    }
+    d->cols = keep;
+    d->bed_rows = nsnp;
+    d->bed.assign(body.begin(), body.end());
+    return;
+  }
+  d->geno.assign((size_t)d->N * d->M, 0);
   for (int c = 0; c < d->M; c++) {
     int s = keep[c];
     d->pos[c] = pos_all[s] / 1000000;  // PLINK_POS_SCALING, src/conf.h:8
@@ -236,7 +250,6 @@ void read_plink(const std::string &bed, const std::string &bim, const std::strin
       d->geno[(size_t)i * d->M + c] = recode[code];
     }
   }
-  std::printf("\t-> Plink file contains %d autosomale SNP's\n", d->M);
 }
 
 // mysort (src/asort.cpp:37-88): order by (chr, pos); equal neighbouring positions abort
@@ -258,10 +271,18 @@ void sort_snps(DataSet *d) {
   s.geno.resize(d->geno.size());
   s.pos.resize(d->M);
   s.chr.resize(d->M);
+  const bool packed = !d->bed.empty();
+  if (packed) s.cols.resize(d->M);
   for (int c = 0; c < d->M; c++) {
     s.pos[c] = d->pos[id[c]];
     s.chr[c] = d->chr[id[c]];
-    for (int i = 0; i < d->N; i++) s.geno[(size_t)i * d->M + c] = d->geno[(size_t)i * d->M + id[c]];
+    if (packed) s.cols[c] = d->cols[id[c]];  // the sort only permutes the row list of the packed payload
+    else
+      for (int i = 0; i < d->N; i++) s.geno[(size_t)i * d->M + c] = d->geno[(size_t)i * d->M + id[c]];
+  }
+  if (packed) {
+    s.bed.swap(d->bed);
+    s.bed_rows = d->bed_rows;
   }
   *d = std::move(s);
 }
@@ -432,8 +453,11 @@ int main(int argc, char **argv) {
   if (relate_hip_create(&h, device)) die(relate_hip_last_error(nullptr));
   std::vector<int> keep(d.M);
   int M = 0;
-  if (relate_hip_load(h, d.geno.data(), d.N, d.M, d.pos.data(), d.chr.data(), &op.o) ||
-      relate_hip_precalc(h, keep.data(), &M))
+  int lrc = d.bed.empty()
+                ? relate_hip_load(h, d.geno.data(), d.N, d.M, d.pos.data(), d.chr.data(), &op.o)
+                : relate_hip_load_bed(h, d.bed.data(), d.N, d.bed_rows, d.cols.data(), d.M, d.pos.data(), d.chr.data(),
+                                      &op.o);
+  if (lrc || relate_hip_precalc(h, keep.data(), &M))
     die(relate_hip_last_error(h));
 
   std::vector<int32_t> pairs;

@@ -34,6 +34,31 @@ __global__ void pack_kernel(const uint8_t *__restrict__ raw, int N, int Mraw, co
   out[(size_t)s * W + w] = word;
 }
 
+// PLINK .bed ingestion without the reference's int matrix (bed_to_iMatrix, src/filereader_and_conversions.cpp:483-564).
+// bed: the SNP-major payload after the 3-byte header, one row of bps = ceil(N/4) bytes per .bim line, four
+// individuals per byte from the low bits up -- the same bit order as the packed layout here, so a 64-bit word of 32
+// individuals is recoded with three logic operations.  PLINK code -> reference code: recode {1,0,2,3} followed by the
+// 1 <-> 3 swap (:485, 530-533), i.e. 00 -> 3, 01 (missing) -> 0, 10 -> 2, 11 -> 1: out_hi = !lo, out_lo = !(hi ^ lo).
+// cols: the Msel .bed rows to use, in analysis order (autosome filter doBimFile :634-640 and mysort src/asort.cpp:37-88
+// are applied to the M-length position vectors by the caller).  One thread per (selected SNP, word).
+__global__ void bed_recode_kernel(const uint8_t *__restrict__ bed, int bps, const int *__restrict__ cols, int Msel, int N,
+                                  int W, uint64_t *__restrict__ out) {
+  long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (long)Msel * W) return;
+  int s = (int)(tid / W), w = (int)(tid % W);
+  const uint8_t *row = bed + (size_t)cols[s] * bps;
+  uint64_t x = 0;
+  int b0 = w * 8;
+#pragma unroll
+  for (int b = 0; b < 8; b++)
+    if (b0 + b < bps) x |= (uint64_t)row[b0 + b] << (8 * b);
+  uint64_t lo = x & kLoMask, hi = (x >> 1) & kLoMask;
+  uint64_t y = ((~lo & kLoMask) << 1) | (~(hi ^ lo) & kLoMask);
+  int left = N - w * 32;  // individuals in this word; padding bits of the last byte are not individuals
+  if (left < 32) y &= (((uint64_t)1 << (2 * left)) - 1);
+  out[tid] = y;
+}
+
 // rows selected from an already packed matrix (pruning / MAF filter on the device copy)
 __global__ void gather_rows_kernel(const uint64_t *__restrict__ in, const int *__restrict__ rows, int Msel, int W,
                                    uint64_t *__restrict__ out) {

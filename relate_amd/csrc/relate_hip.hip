@@ -59,6 +59,9 @@ struct relate_hip_ctx {
   int N = 0, Mraw = 0, M = 0, W = 0;
   int useLD = 0;
   std::vector<uint8_t> h_raw;
+  std::vector<uint8_t> h_bed;    // relate_hip_load_bed: SNP-major .bed payload (h_raw stays empty)
+  std::vector<int> h_bedcols;    // its rows in analysis order
+  int bedBps = 0;
   std::vector<double> h_pos_raw;
   std::vector<int> h_chr_raw;
   std::vector<int> keep;  // Mraw: pre_calc_used_list
@@ -616,6 +619,38 @@ int relate_hip_load(relate_hip_t h, const uint8_t *geno, int N, int M_raw, const
   h->Mraw = M_raw;
   h->W = (N + 31) / 32;
   h->h_raw.assign(geno, geno + (size_t)N * M_raw);
+  h->h_bed.clear();
+  h->h_bed.shrink_to_fit();
+  h->h_bedcols.clear();
+  h->h_pos_raw.assign(pos, pos + M_raw);
+  if (chr) h->h_chr_raw.assign(chr, chr + M_raw);
+  else h->h_chr_raw.assign(M_raw, -1);
+  h->loaded = true;
+  h->ready = false;
+  h->staged.clear();
+  return RELATE_OK;
+}
+
+int relate_hip_load_bed(relate_hip_t h, const uint8_t *bed, int N, int n_snp_bed, const int *cols, int M_raw,
+                        const double *pos, const int *chr, const relate_opts *opts) {
+  if (!h) return fail(nullptr, RELATE_E_ARG, "null handle");
+  if (!bed || !cols || !pos || !opts || N < 2 || M_raw < 2 || n_snp_bed < M_raw)
+    return fail(h, RELATE_E_ARG, "bad data set arguments");
+  if (opts->doPrune && opts->back == 0)
+    return fail(h, RELATE_E_ARG, "Must supply a back > 0, when you want to prune (src/runRelate.cpp:89-92)");
+  if (opts->back < 0) return fail(h, RELATE_E_ARG, "back must be >= 0");
+  for (int s = 0; s < M_raw; s++)
+    if (cols[s] < 0 || cols[s] >= n_snp_bed) return fail(h, RELATE_E_ARG, "a .bed row index is out of range");
+  h->o = *opts;
+  h->back2 = 2 * opts->back;
+  h->N = N;
+  h->Mraw = M_raw;
+  h->W = (N + 31) / 32;
+  h->bedBps = (N + 3) / 4;
+  h->h_bed.assign(bed, bed + (size_t)n_snp_bed * h->bedBps);
+  h->h_bedcols.assign(cols, cols + M_raw);
+  h->h_raw.clear();
+  h->h_raw.shrink_to_fit();
   h->h_pos_raw.assign(pos, pos + M_raw);
   if (chr) h->h_chr_raw.assign(chr, chr + M_raw);
   else h->h_chr_raw.assign(M_raw, -1);
@@ -647,12 +682,23 @@ int relate_hip_precalc(relate_hip_t h, int *keep_out, int *M_out) {
                   std::string(#expr) + ": " + hipGetErrorString(e_));                                  \
     }                                                                                                  \
   } while (0)
-  PCHK(dRaw.ensure((size_t)N * Mraw));
-  PCHK(hipMemcpyAsync(dRaw.p, h->h_raw.data(), (size_t)N * Mraw, hipMemcpyHostToDevice, st));
   PCHK(dG0.ensure((size_t)Mraw * W));
-  hipLaunchKernelGGL(pack_kernel, dim3(blocks_for((long)Mraw * W, 256)), dim3(256), 0, st, dRaw.p, N, Mraw,
-                     (const int *)nullptr, Mraw, W, dG0.p);
-  PCHK(hipGetLastError());
+  if (!h->h_bed.empty()) {  // PLINK payload: recode the 2-bit fields in place of the byte matrix
+    PCHK(dRaw.ensure(h->h_bed.size()));
+    PCHK(hipMemcpyAsync(dRaw.p, h->h_bed.data(), h->h_bed.size(), hipMemcpyHostToDevice, st));
+    PCHK(dCols.ensure(Mraw));
+    PCHK(hipMemcpyAsync(dCols.p, h->h_bedcols.data(), sizeof(int) * Mraw, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(bed_recode_kernel, dim3(blocks_for((long)Mraw * W, 256)), dim3(256), 0, st, dRaw.p, h->bedBps,
+                       dCols.p, Mraw, N, W, dG0.p);
+    PCHK(hipGetLastError());
+    PCHK(hipStreamSynchronize(st));  // dCols is reused below
+  } else {
+    PCHK(dRaw.ensure((size_t)N * Mraw));
+    PCHK(hipMemcpyAsync(dRaw.p, h->h_raw.data(), (size_t)N * Mraw, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(pack_kernel, dim3(blocks_for((long)Mraw * W, 256)), dim3(256), 0, st, dRaw.p, N, Mraw,
+                       (const int *)nullptr, Mraw, W, dG0.p);
+    PCHK(hipGetLastError());
+  }
   // K1 on all raw SNPs, maf_stripper on the host copy of M_raw doubles (:3302-3305)
   PCHK(dMaf0.ensure(Mraw));
   hipLaunchKernelGGL(maf_kernel, dim3(blocks_for(Mraw, 256)), dim3(256), 0, st, dG0.p, Mraw, W, dMaf0.p);

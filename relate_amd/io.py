@@ -122,6 +122,42 @@ def load_plink(prefix):
     return sort_snps(np.ascontiguousarray(g[:, keep]), poss[keep], chrs[keep])
 
 
+def read_plink_raw(prefix):
+    """PLINK input for relate_hip_load_bed: the .bed payload as it lies in the file (SNP-major only) plus the short
+    per-SNP vectors after doBimFile's autosome filter and mysort -- the genotype matrix itself is never unpacked on
+    the host.  Returns (payload uint8[n_snp * ceil(N/4)], N, cols, pos, chr)."""
+    chrs, poss = [], []
+    with open(prefix + ".bim") as fh:
+        for line in fh:
+            t = line.split()
+            if not t:
+                break
+            if len(t) != 6:
+                raise ValueError("plink bim file doesn't have 6 columns")
+            chrs.append(int(t[0]))
+            poss.append(float(t[3]))
+    with open(prefix + ".fam") as fh:
+        n_ind = sum(1 for line in fh if line.strip())
+    raw = np.fromfile(prefix + ".bed", dtype=np.uint8)
+    if raw[0] != 0x6C or raw[1] != 0x1B:
+        raise ValueError("Input file does not appear to be a .bed file")
+    if not raw[2]:
+        raise ValueError("individual-major .bed: use load_plink()")
+    nsnp = len(chrs)
+    bps = (n_ind + 3) // 4
+    if raw.size < 3 + nsnp * bps:
+        raise ValueError("Unexpected end of file reached")
+    chrs = np.array(chrs, dtype=np.int32)
+    poss = np.array(poss) / 1000000  # PLINK_POS_SCALING
+    rows = np.nonzero((chrs != 0) & (chrs < 23))[0]
+    order = np.lexsort((poss[rows], chrs[rows]))
+    cols = rows[order].astype(np.int32)
+    p = poss[cols]
+    if len(p) > 1 and (p[1:] == p[:-1]).any():
+        raise ValueError("Non unique position")
+    return raw[3:3 + nsnp * bps], n_ind, cols, np.ascontiguousarray(p), np.ascontiguousarray(chrs[cols])
+
+
 def keep_list_pairs(path):
     idx = [i for i, f in enumerate(read_vector(path, int)) if f == 1]
     return np.array([(a, b) for n, a in enumerate(idx) for b in idx[n + 1:]], dtype=np.int32).reshape(-1, 2)
