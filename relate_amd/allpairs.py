@@ -9,6 +9,13 @@ Outputs: every rank writes the posterior rows of its shard to <out>.post.rank<r>
 .post format: concatenating the shards in rank order gives the single-process .post); rank 0 writes <out>.k (the
 reference's format) and <out>.est (pair, a, k2, k1, -logL, runs, converged, nsnp, status at full precision) for
 ALL pairs after the gather.  Posteriors are never gathered: at config 4 they are terabytes.
+-post-format bin writes <out>.postbin.rank<r> instead: the same rows as raw little-endian float32, M values per row
+(-1 = SNP dropped for the pair), with <out>.postbin.rank<r>.json = {"rows", "snps", "rows_per_pair", "first_pair"} --
+the shard format for data sets whose text .post would not be practical (4 significant digits fit a float32).
+
+Work is cut twice: the fit runs on blocks of -block pairs (default 8192: with a few thousand pairs in flight the
+likelihood launches are single sweeps rather than chunked ones), and the posteriors of a fitted block are decoded
+and written in sub-blocks bounded by a 1 GiB host buffer.
 
 SURVEY.md section 8(e); pair order: fast_all_pairs / joblist_fast_all_pairs (src/relateHMM.cpp:3764-3765, 3851).
 """
@@ -33,7 +40,10 @@ def parse_args(argv=None):
     ap.add_argument("-out", dest="out", default="relate_out")
     ap.add_argument("-seed", dest="seed", type=int, default=None)
     ap.add_argument("-no-post", dest="no_post", action="store_true")
-    ap.add_argument("-block", dest="block", type=int, default=0, help="pairs per library call (0 = by memory)")
+    ap.add_argument("-block", dest="block", type=int, default=0, help="pairs per fit call (0 = 8192)")
+    ap.add_argument("-post-block", dest="post_block", type=int, default=0,
+                    help="pairs per posterior decode call (0 = what a 1 GiB host buffer holds)")
+    ap.add_argument("-post-format", dest="post_format", choices=("text", "bin"), default="text")
     return ap.parse_args(argv)
 
 
@@ -68,21 +78,45 @@ def run(a, handle_factory, dist=None, coll_device=None):
     H = handle_factory()
     M = H.init_globals(geno, pos, chr_, opt)
     k1_only = opt["fixK"] == 1 and opt["fixK_val"] == 0
-    block = a.block if a.block > 0 else max(1, min(len(mine) or 1, (1 << 30) // (24 * M)))
+    block = a.block if a.block > 0 else 8192
+    post_block = getattr(a, "post_block", 0) or max(1, min(block, (1 << 30) // (24 * M)))
     fits = []
-    post_path = "%s.post.rank%d" % (a.out, rank)
-    fh = None if a.no_post else open(post_path, "w")
+    binary = getattr(a, "post_format", "text") == "bin"
+    post_path = "%s.%s.rank%d" % (a.out, "postbin" if binary else "post", rank)
+    fh = None if a.no_post else open(post_path, "wb" if binary else "w")
+    nrows = 0
     try:
         for b0 in range(0, len(mine), block):
             blk = mine[b0:b0 + block]
-            res, post, _ = H.sgl(blk, want_post=not a.no_post)
+            if fh is None or len(blk) <= post_block:
+                res, post, _ = H.sgl(blk, want_post=fh is not None)
+                chunks = [(0, post)]
+            else:
+                res, _, _ = H.sgl(blk, want_post=False)   # fit (+ SNP counts); posteriors follow in sub-blocks
+                chunks = ((c0, None) for c0 in range(0, len(blk), post_block))
             fits.extend(res)
-            if fh is not None:
-                for n in range(len(blk)):
-                    rio.write_post_rows(fh, post[n], k1_only)
+            if fh is None:
+                continue
+            for c0, post in chunks:
+                if post is None:
+                    sub = blk[c0:c0 + post_block]
+                    par = [(r["a"], r["k2"], r["k1"]) for r in res[c0:c0 + post_block]]
+                    post, _, _ = H.decode(sub, par)
+                for n in range(len(post)):
+                    if binary:
+                        for row in ((2,) if k1_only else (2, 1)):
+                            fh.write(np.asarray(post[n][row], dtype="<f4").tobytes())
+                    else:
+                        rio.write_post_rows(fh, post[n], k1_only)
+                    nrows += 1 if k1_only else 2
     finally:
         if fh is not None:
             fh.close()
+    if binary and not a.no_post:
+        import json
+        with open(post_path + ".json", "w") as fj:
+            json.dump({"rows": nrows, "snps": int(M), "rows_per_pair": 1 if k1_only else 2, "first_pair": int(b),
+                       "dtype": "<f4", "missing": -1}, fj)
     local = rdist.fits_to_array(fits)
     full = rdist.gather_rows(local, len(pairs), device=coll_device) if dist is not None else local
     if rank == 0:

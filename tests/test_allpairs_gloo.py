@@ -24,7 +24,15 @@ class FakeHandle:
                             poLike=0.0, timesRun=1, timesConverged=1, nsnp=self.M, status=0))
             post[n] = (i * 100 + j) / 1e4
             post[n][:, 3] = -1
-        return res, post, None
+        return res, (post if want_post else None), None
+
+    def decode(self, pairs, params, **kw):
+        post = np.zeros((len(pairs), 3, self.M))
+        for n, (i, j) in enumerate(pairs):
+            assert abs(params[n][2] - (i * 100 + j) / 1e4) < 1e-15   # decoded at the fitted k1 of that pair
+            post[n] = (i * 100 + j) / 1e4
+            post[n][:, 3] = -1
+        return post, None, np.full(len(pairs), self.M, dtype=np.int32)
 
 
 def _free_port():
@@ -35,7 +43,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, extra=()):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -45,7 +53,7 @@ def _worker(rank, world, port, out):
     from test_allpairs_gloo import FakeHandle
     dist.init_process_group("gloo", rank=rank, world_size=world)
     a = allpairs.parse_args(["-o", DATA + "/options.linkage.txt", "-file", DATA + "/dat_small", "-d",
-                             DATA + "/dat_small.keep", "-out", out, "-seed", "1", "-block", "17"])
+                             DATA + "/dat_small.keep", "-out", out, "-seed", "1", "-block", "17"] + list(extra))
     allpairs.run(a, FakeHandle, dist, torch.device("cpu"))
     dist.barrier()
     dist.destroy_process_group()
@@ -75,3 +83,34 @@ def test_two_rank_allpairs_outputs(tmp_path):
     for (i, j), row in zip(pairs, rows):
         t = row.split("\t")
         assert t[-1] == "" and len(t) == 8 and t[3] == "-1" and float(t[0]) == float("%.4g" % ((i * 100 + j) / 1e4))
+
+
+def test_two_rank_binary_shards_with_post_subblocks(tmp_path):
+    """fit blocks of 17 pairs, posteriors decoded 5 pairs at a time, written as float32 shards"""
+    import json
+    out = os.path.join(tmp_path, "runb")
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    extra = ("-post-block", "5", "-post-format", "bin")
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, extra)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    sys.path.insert(0, ROOT)
+    from relate_amd import io as rio
+    pairs = rio.keep_list_pairs(DATA + "/dat_small.keep")
+    rows = []
+    first = []
+    for r in range(2):
+        meta = json.load(open("%s.postbin.rank%d.json" % (out, r)))
+        assert meta["snps"] == 7 and meta["rows_per_pair"] == 1
+        first.append(meta["first_pair"])
+        x = np.fromfile("%s.postbin.rank%d" % (out, r), dtype="<f4").reshape(meta["rows"], meta["snps"])
+        rows.append(x)
+    assert first == [0, 95]
+    x = np.concatenate(rows)
+    assert x.shape == (190, 7)
+    want = np.array([(i * 100 + j) / 1e4 for i, j in pairs], dtype=np.float32)
+    assert np.array_equal(x[:, 0], want) and np.all(x[:, 3] == -1)
