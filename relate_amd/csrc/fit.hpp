@@ -240,8 +240,9 @@ class FindMax {
   }
 };
 
-// multi-start rule of run_optimization for one pair; runs are launched in waves of the minimum number
-// that could still be needed, and consumed strictly in index order, so the outcome equals the sequential loop.
+// multi-start rule of run_optimization for one pair; runs are launched in waves (the minimum number that could
+// still be needed, or all remaining ones once the first wave has shown no agreement) and consumed strictly in index
+// order, so the outcome equals the sequential loop.
 struct MultiStart {
   int timesToConverge = 1, timesToRun = 1;
   double convTol = 0.1;
@@ -257,6 +258,10 @@ struct MultiStart {
     int need = timesToConverge - conv;
     if (need < 1) need = 1;
     int room = timesToRun - launched;
+    // No two runs have agreed so far: expect to need every remaining run and start them together, so that the
+    // likelihood launches keep enough lanes to fill the machine.  Results are still consumed strictly in index
+    // order and the rule stops where the sequential loop stops; runs beyond that point are discarded unseen.
+    if (conv <= 1 && consumed >= 2) return room;
     return need < room ? need : room;
   }
   void consume(const double *res) {  // res = {a,k2,k1,negloglik} of run `consumed`

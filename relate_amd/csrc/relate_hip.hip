@@ -10,8 +10,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "fit.hpp"
@@ -110,6 +112,34 @@ int fail(relate_hip_t h, int code, const std::string &msg) {
 
 inline unsigned blocks_for(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
+// Host-side control work of the batched optimiser (one L-BFGS-B step and the objective wrappers of every active run
+// per round) spread over a few threads: runs are independent objects.  RELATE_HOST_THREADS overrides (default: up to 8).
+int host_threads() {
+  static int n = [] {
+    int v = 0;
+    if (const char *e = getenv("RELATE_HOST_THREADS")) v = atoi(e);
+    if (v < 1) {
+      v = (int)std::thread::hardware_concurrency();
+      if (v > 8) v = 8;
+    }
+    return v < 1 ? 1 : v;
+  }();
+  return n;
+}
+template <class F>
+void parallel_for(size_t n, F &&fn) {  // fn(begin, end)
+  int nt = host_threads();
+  if (n < 4096 || nt == 1) { fn((size_t)0, n); return; }
+  std::vector<std::thread> th;
+  size_t per = (n + nt - 1) / nt;
+  for (int t = 0; t < nt; t++) {
+    size_t lo = (size_t)t * per, hi = std::min(n, lo + per);
+    if (lo >= hi) break;
+    th.emplace_back([&fn, lo, hi] { fn(lo, hi); });
+  }
+  for (auto &x : th) x.join();
+}
+
 // Row pitch of the staged record block: P rounded up to 64 records (2 KiB), then made an odd number of 2 KiB units,
 // so that consecutive SNP rows never lie a power of two apart (HBM channel camping of the strided sweeps).  Small
 // blocks stay dense.
@@ -179,17 +209,21 @@ int stage_block(relate_hip_t h, const int32_t *pairs, int P) {
 
 // SNP-axis chunking.  A sweep lane carries a serial chain of M steps; below about two waves per SIMD the
 // machine idles, so the SNP axis is cut until there are enough threads -- but a chunked step costs ~2x a plain
-// one, so a launch that already has >= ~1.5 waves per SIMD stays a single sweep.  When cutting, the number of
+// one, so a launch that already has >= ~0.7 waves per SIMD stays a single sweep (g_single_sweep_lanes).  When cutting, the number of
 // chunks is the largest one whose waves still fit `rounds` full turns of the `slots` waves the kernels of the launch
 // can hold at once (hipOccupancy at create time; for decode the least common multiple over its three kernels): one
 // chunk more would add a turn that runs nearly empty (a seventh of the run time at 6 turns).  The likelihood uses
 // 12 turns; decode one turn of the common multiple (its combine kernel walks the chunks serially per pair and its
 // sweeps are HBM-bound, not latency-bound).  Chunks are multiples of 16 SNPs (the posterior tiles of
 // decode_bwd_kernel) and at least 512 SNPs long.
+// Launches with at least this many lanes run as one sweep per lane; fewer are cut along the SNP axis.  Measured
+// crossover (M = 1e5): a lone wave per SIMD walks its chain in 10.4 ms whatever the lane count, the chunked path
+// sustains ~420 G lane-steps/s, equal at ~44 000 lanes.  RELATE_SINGLE_SWEEP_LANES overrides (tuning experiments).
+long g_single_sweep_lanes = 45056;
+
 void pick_chunks(int M, long lanes, int wg_threads, long slots, int rounds, int *nchunk, int *chunk_len) {
-  const long simd_lanes = 256L * 4 * 64;  // one wave on every SIMD
   long c = 1;
-  if (lanes < simd_lanes * 3 / 2) {
+  if (lanes < g_single_sweep_lanes) {
     long wg = (lanes + wg_threads - 1) / wg_threads;
     long waves_per_chunk = wg * ((wg_threads + 63) / 64);
     c = (slots * rounds) / std::max(1L, waves_per_chunk);
@@ -234,12 +268,23 @@ int launch_like(relate_hip_t h, int P, int nl) {
   h->last_chunks[0] = nchunk;
   const bool dr = h->o.double_recom != 0;
   if (nchunk == 1) {
-    if (dr)
-      hipLaunchKernelGGL(like_kernel<true>, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch,
-                         h->dLanePair.p, h->dParams.p, nl, h->o.alim[1], h->dOut.p);
-    else
-      hipLaunchKernelGGL(like_kernel<false>, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch,
-                         h->dLanePair.p, h->dParams.p, nl, h->o.alim[1], h->dOut.p);
+    // ring depth by the waves per SIMD this launch can fill (kernels_hmm.hpp, like_kernel)
+    const long simd_lanes = 256L * 4 * 64;
+    const int nbuf = nl <= simd_lanes ? 6 : (nl <= 2 * simd_lanes ? 4 : 2);
+    dim3 grid(blocks_for(nl, 256)), block(256);
+#define LAUNCH_LIKE(DR, NB)                                                                                        \
+  hipLaunchKernelGGL((like_kernel<DR, NB>), grid, block, 0, h->stream, h->dRec.p, h->M, h->recPitch, h->dLanePair.p, \
+                     h->dParams.p, nl, h->o.alim[1], h->dOut.p)
+    if (dr) {
+      if (nbuf == 6) LAUNCH_LIKE(true, 6);
+      else if (nbuf == 4) LAUNCH_LIKE(true, 4);
+      else LAUNCH_LIKE(true, 2);
+    } else {
+      if (nbuf == 6) LAUNCH_LIKE(false, 6);
+      else if (nbuf == 4) LAUNCH_LIKE(false, 4);
+      else LAUNCH_LIKE(false, 2);
+    }
+#undef LAUNCH_LIKE
     HIPCHK(h, hipGetLastError());
     return 0;
   }
@@ -279,6 +324,8 @@ int like_lanes(relate_hip_t h, int P, const int32_t *lane_pair, const double *pa
   float ms = 0;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
   h->timings[1] += ms;
+  if (getenv("RELATE_FIT_TRACE"))
+    std::fprintf(stderr, "like launch: %d lanes, %d chunks, %.3f ms\n", nl, h->last_chunks[0], ms);
   return 0;
 }
 
@@ -338,6 +385,12 @@ int fit_block(relate_hip_t h, int P, const int32_t *pairs, long pair_base, const
     FindMax fm;
     int pair, idx;
     std::vector<int> slot;  // for each requested point: index into val, or -1 if the wrapper short-circuits
+    bool waited = false;    // its request was held back in the previous round
+    bool taken = true;      // its request is part of this round's launch
+    double akk[7][3];       // the request mapped to (a, k2, k1)
+    bool ok[7];
+    int nlanes = 0;
+    bool bad = false;
   };
   std::vector<MultiStart> ms(P);
   std::vector<GlibcRand> rng;
@@ -390,6 +443,15 @@ int fit_block(relate_hip_t h, int P, const int32_t *pairs, long pair_base, const
       for (int p = 0; p < P; p++)
         while (!ms[p].finished && ms[p].consumed < ms[p].launched && have[p][ms[p].consumed])
           ms[p].consume(&results[p][(size_t)ms[p].consumed * 4]);
+      // runs started ahead of need for a pair whose rule has stopped meanwhile are dropped unseen
+      for (size_t i = 0; i < active.size();) {
+        if (ms[active[i]->pair].finished) {
+          delete active[i];
+          active[i] = active.back();
+          active.pop_back();
+        } else
+          i++;
+      }
       bool relaunch = false;
       for (int p = 0; p < P; p++)
         if (ms[p].want_to_launch() > 0) relaunch = true;
@@ -402,15 +464,50 @@ int fit_block(relate_hip_t h, int P, const int32_t *pairs, long pair_base, const
     if (active.empty() && !first_round) break;
     // gather the requested points of every active run into one launch
     if (!first_round) { lp.clear(); par.clear(); }
-    size_t base = lp.size();
-    (void)base;
+    // lanes of one pair side by side: they read the same records, so a wave touches ~13 distinct records per step
+    // instead of 64 (retiring runs swaps the list around; measured 250 -> 330 G lane-steps/s on the chunked path)
+    std::sort(active.begin(), active.end(), [](const Run *x, const Run *y) {
+      return x->pair != y->pair ? x->pair < y->pair : x->idx < y->idx;
+    });
+    // Whole turns of the machine.  A single sweep costs the time of its fullest SIMD: 100 000 steps take 10.4 ms
+    // with up to one wave per SIMD (65 536 lanes), 17.5 ms with up to two, 26 ms with up to three, so 70 000 lanes
+    // cost as much as 131 072.  A round with more than one full turn of requests launches whole turns only and
+    // holds the rest back one round (runs are independent state machines; a held request is simply answered later,
+    // with the same values).  Held runs go first in the next round, so none waits twice.
+    const long kTurn = 256L * 4 * 64;
+    long want = 0;
+    parallel_for(active.size(), [&](size_t lo_, size_t hi_) {
+      for (size_t i = lo_; i < hi_; i++) {  // lanes a run needs: the points its wrapper does not short-circuit
+        Run *r = active[i];
+        r->nlanes = 0;
+        for (int q = 0; q < r->fm.npts; q++) {
+          r->ok[q] = map_point(S, r->fm.pts[q], r->akk[q]);
+          r->nlanes += r->ok[q] ? 1 : 0;
+        }
+      }
+    });
+    for (Run *r : active) want += r->nlanes;
+    long budget = (!first_round && want > kTurn) ? (want / kTurn) * kTurn : want;
+    long used = 0;
     for (Run *r : active) {
+      r->taken = r->waited;
+      if (r->taken) used += r->nlanes;
+    }
+    for (Run *r : active) {
+      if (r->taken) continue;
+      if (used + r->nlanes <= budget) {
+        r->taken = true;
+        used += r->nlanes;
+      }
+    }
+    for (Run *r : active) {
+      r->waited = !r->taken;
+      if (!r->taken) continue;
       r->slot.assign(r->fm.npts, -1);
       for (int q = 0; q < r->fm.npts; q++) {
-        double akk[3];
-        if (map_point(S, r->fm.pts[q], akk)) {
+        if (r->ok[q]) {
           r->slot[q] = (int)lp.size();
-          push(r->pair, akk[0], akk[1], akk[2]);
+          push(r->pair, r->akk[q][0], r->akk[q][1], r->akk[q][2]);
         }
       }
     }
@@ -427,20 +524,26 @@ int fit_block(relate_hip_t h, int P, const int32_t *pairs, long pair_base, const
       }
       first_round = false;
     }
-    for (Run *r : active) {
-      double v[7];
-      for (int q = 0; q < r->fm.npts; q++) v[q] = r->slot[q] < 0 ? kSysMax : val[r->slot[q]];
-      bool bad = false;
-      for (int q = 0; q < r->fm.npts; q++)
-        if (!std::isfinite(v[q])) bad = true;
-      if (bad) {  // the reference prints and exit(0)s on NaN (:1513-1520); flag the pair and stop this run
-        out[r->pair].status = RELATE_E_NUMERIC;
-        r->fm.done = true;
-        r->fm.like = NAN;
-        continue;
+    parallel_for(active.size(), [&](size_t lo_, size_t hi_) {
+      for (size_t i = lo_; i < hi_; i++) {
+        Run *r = active[i];
+        if (!r->taken) continue;
+        double v[7];
+        for (int q = 0; q < r->fm.npts; q++) v[q] = r->slot[q] < 0 ? kSysMax : val[r->slot[q]];
+        bool bad = false;
+        for (int q = 0; q < r->fm.npts; q++)
+          if (!std::isfinite(v[q])) bad = true;
+        if (bad) {  // the reference prints and exit(0)s on NaN (:1513-1520); flag the pair and stop this run
+          r->bad = true;
+          r->fm.done = true;
+          r->fm.like = NAN;
+          continue;
+        }
+        r->fm.supply(v);
       }
-      r->fm.supply(v);
-    }
+    });
+    for (Run *r : active)
+      if (r->bad) out[r->pair].status = RELATE_E_NUMERIC;
     if (active.empty()) break;
   }
   for (int p = 0; p < P; p++) {
@@ -451,7 +554,8 @@ int fit_block(relate_hip_t h, int P, const int32_t *pairs, long pair_base, const
     out[p].negloglik = ms[p].best[3];
     out[p].timesRun = ms[p].consumed;
     out[p].timesConverged = ms[p].conv;
-    if (conv_out) std::memcpy(conv_out + (size_t)(pair_base + p) * R * 4, results[p].data(), sizeof(double) * R * 4);
+    if (conv_out)  // convInfo: the runs the rule consumed; rows beyond stay zero (speculative runs are not reported)
+      std::memcpy(conv_out + (size_t)(pair_base + p) * R * 4, results[p].data(), sizeof(double) * ms[p].consumed * 4);
   }
   (void)pairs;
   return 0;
@@ -559,6 +663,7 @@ int relate_hip_create(relate_hip_t *out, int device_id) {
                 std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
                     " (librelate_hip has no CPU fallback)");
   if (device_id < 0 || device_id >= ndev) return fail(nullptr, RELATE_E_ARG, "device_id out of range");
+  if (const char *e = getenv("RELATE_SINGLE_SWEEP_LANES")) g_single_sweep_lanes = atol(e);
   relate_hip_ctx *h = new relate_hip_ctx();
   h->dev = device_id;
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
