@@ -13,9 +13,10 @@ ALL pairs after the gather.  Posteriors are never gathered: at config 4 they are
 (-1 = SNP dropped for the pair), with <out>.postbin.rank<r>.json = {"rows", "snps", "rows_per_pair", "first_pair"} --
 the shard format for data sets whose text .post would not be practical (4 significant digits fit a float32).
 
-Work is cut twice: the fit runs on blocks of -block pairs (default 8192: with a few thousand pairs in flight the
-likelihood launches are single sweeps rather than chunked ones), and the posteriors of a fitted block are decoded
-and written in sub-blocks bounded by a 1 GiB host buffer.
+Work is cut twice: the fit runs on as many pairs at a time as device memory holds records for (the library cuts a
+call of -block pairs itself; with tens of thousands of lanes in flight the likelihood launches are whole turns of
+single sweeps rather than chunked ones), and the posteriors of a fitted block are decoded and written in sub-blocks
+bounded by a 1 GiB host buffer.
 
 SURVEY.md section 8(e); pair order: fast_all_pairs / joblist_fast_all_pairs (src/relateHMM.cpp:3764-3765, 3851).
 """
@@ -40,7 +41,8 @@ def parse_args(argv=None):
     ap.add_argument("-out", dest="out", default="relate_out")
     ap.add_argument("-seed", dest="seed", type=int, default=None)
     ap.add_argument("-no-post", dest="no_post", action="store_true")
-    ap.add_argument("-block", dest="block", type=int, default=0, help="pairs per fit call (0 = 8192)")
+    ap.add_argument("-block", dest="block", type=int, default=0,
+                    help="pairs per library call (0 = 65536; the library cuts a call into the blocks its memory holds)")
     ap.add_argument("-post-block", dest="post_block", type=int, default=0,
                     help="pairs per posterior decode call (0 = what a 1 GiB host buffer holds)")
     ap.add_argument("-post-format", dest="post_format", choices=("text", "bin"), default="text")
@@ -78,7 +80,7 @@ def run(a, handle_factory, dist=None, coll_device=None):
     H = handle_factory()
     M = H.init_globals(geno, pos, chr_, opt)
     k1_only = opt["fixK"] == 1 and opt["fixK_val"] == 0
-    block = a.block if a.block > 0 else 8192
+    block = a.block if a.block > 0 else 65536
     post_block = getattr(a, "post_block", 0) or max(1, min(block, (1 << 30) // (24 * M)))
     fits = []
     binary = getattr(a, "post_format", "text") == "bin"

@@ -155,10 +155,12 @@ int set_device(relate_hip_t h) {
   return 0;
 }
 
-size_t pair_block_limit(relate_hip_t h, size_t bytes_per_pair_snp) {
+// Pairs per block such that bytes_per_pair_snp x M x pairs fits in 70 % of the memory that is free now plus `held`
+// bytes the (grow-only) buffers for that purpose already own.
+size_t pair_block_limit(relate_hip_t h, size_t bytes_per_pair_snp, size_t held = 0) {
   size_t freeb = 0, total = 0;
   if (hipMemGetInfo(&freeb, &total) != hipSuccess) freeb = (size_t)8 << 30;
-  size_t budget = (size_t)(0.70 * (double)freeb);
+  size_t budget = (size_t)(0.70 * (double)freeb) + held;
   size_t per_pair = bytes_per_pair_snp * (size_t)h->M + 256;
   size_t lim = budget / per_pair;
   if (lim < 1) lim = 1;
@@ -1033,7 +1035,7 @@ int relate_hip_like(relate_hip_t h, const int32_t *pairs, int P, const double *p
   if (rc) return rc;
   if (!pairs || !params || !negloglik || P < 0 || E < 1) return fail(h, RELATE_E_ARG, "bad arguments");
   h->timings[1] = 0;
-  size_t lim = pair_block_limit(h, sizeof(EmisRec));
+  size_t lim = pair_block_limit(h, sizeof(EmisRec), h->dRec.cap * sizeof(EmisRec));
   std::vector<int32_t> lp;
   for (long b0 = 0; b0 < P; b0 += (long)lim) {
     int pb = (int)std::min<long>((long)lim, P - b0);
@@ -1055,7 +1057,7 @@ int relate_hip_fit(relate_hip_t h, const int32_t *pairs, int P, const double *st
   if (!pairs || !out || P < 0) return fail(h, RELATE_E_ARG, "bad arguments");
   h->timings[1] = 0;
   if (conv_out) std::memset(conv_out, 0, sizeof(double) * (size_t)P * std::max(1, h->o.timesToRun) * 4);
-  size_t lim = pair_block_limit(h, sizeof(EmisRec));
+  size_t lim = pair_block_limit(h, sizeof(EmisRec), h->dRec.cap * sizeof(EmisRec));
   for (long b0 = 0; b0 < P; b0 += (long)lim) {
     int pb = (int)std::min<long>((long)lim, P - b0);
     rc = stage_block(h, pairs + 2 * b0, pb);
@@ -1072,7 +1074,8 @@ int relate_hip_decode(relate_hip_t h, const int32_t *pairs, int P, const double 
   if (rc) return rc;
   if (!pairs || !params || P < 0) return fail(h, RELATE_E_ARG, "bad arguments");
   h->timings[2] = h->timings[3] = 0;
-  size_t lim = pair_block_limit(h, sizeof(EmisRec) + 3 * sizeof(double) + 8);
+  size_t lim = pair_block_limit(h, sizeof(EmisRec) + 3 * sizeof(double) + 8,
+                                h->dRec.cap * sizeof(EmisRec) + (h->dPost.cap + h->dFwd.cap) * sizeof(double));
   for (long b0 = 0; b0 < P; b0 += (long)lim) {
     int pb = (int)std::min<long>((long)lim, P - b0);
     rc = stage_block(h, pairs + 2 * b0, pb);
@@ -1090,7 +1093,10 @@ int relate_hip_run_pairs(relate_hip_t h, const int32_t *pairs, int P, const doub
   if (rc) return rc;
   if (!pairs || !out || P < 0) return fail(h, RELATE_E_ARG, "bad arguments");
   h->timings[1] = h->timings[2] = h->timings[3] = 0;
-  size_t lim = pair_block_limit(h, sizeof(EmisRec) + 3 * sizeof(double) + 8);
+  // The fit wants as many pairs in flight as the records allow (its launches are single sweeps only with tens of
+  // thousands of lanes); the posteriors of a fitted block are then decoded in sub-blocks sized to what is left for
+  // the 30 B per (pair, SNP) of posterior and checkpoint buffers (a sub-block is re-staged into the same records).
+  size_t lim = pair_block_limit(h, sizeof(EmisRec), h->dRec.cap * sizeof(EmisRec));
   std::vector<double> par;
   std::vector<int> ns;
   for (long b0 = 0; b0 < P; b0 += (long)lim) {
@@ -1099,15 +1105,23 @@ int relate_hip_run_pairs(relate_hip_t h, const int32_t *pairs, int P, const doub
     if (rc) return rc;
     rc = fit_block(h, pb, pairs + 2 * b0, b0, starts, out + b0, nullptr);
     if (rc) return rc;
-    par.resize((size_t)3 * pb);
-    ns.resize(pb);
-    for (int p = 0; p < pb; p++) {
-      par[3 * p] = out[b0 + p].a; par[3 * p + 1] = out[b0 + p].k2; par[3 * p + 2] = out[b0 + p].k1;
+    size_t dlim = pair_block_limit(h, 3 * sizeof(double) + 8, (h->dPost.cap + h->dFwd.cap) * sizeof(double));
+    if (dlim > (size_t)pb) dlim = pb;
+    for (long c0 = 0; c0 < pb; c0 += (long)dlim) {
+      int pc = (int)std::min<long>((long)dlim, pb - c0);
+      rc = stage_block(h, pairs + 2 * (b0 + c0), pc);
+      if (rc) return rc;
+      par.resize((size_t)3 * pc);
+      ns.resize(pc);
+      for (int p = 0; p < pc; p++) {
+        const relate_fit &f = out[b0 + c0 + p];
+        par[3 * p] = f.a; par[3 * p + 1] = f.k2; par[3 * p + 2] = f.k1;
+      }
+      rc = decode_block(h, pc, par.data(), post ? post + (size_t)(b0 + c0) * 3 * h->M : nullptr,
+                        path ? path + (size_t)(b0 + c0) * h->M : nullptr, ns.data(), true);
+      if (rc) return rc;
+      for (int p = 0; p < pc; p++) out[b0 + c0 + p].nsnp = ns[p];
     }
-    rc = decode_block(h, pb, par.data(), post ? post + (size_t)b0 * 3 * h->M : nullptr,
-                      path ? path + (size_t)b0 * h->M : nullptr, ns.data(), true);
-    if (rc) return rc;
-    for (int p = 0; p < pb; p++) out[b0 + p].nsnp = ns[p];
   }
   return RELATE_OK;
 }
