@@ -264,6 +264,12 @@ def test_scale_properties_chunked_equals_unchunked(gpu, oracle):
     np.testing.assert_allclose(bvals[:3, 0], a[:, 0], rtol=1e-12)
     np.testing.assert_allclose(bvals[:3, 1], a[:, 1], rtol=1e-12)
     assert np.ptp(bvals[:, 2:], axis=1).max() == 0                            # identical lanes, identical values
+    # the single sweep has three builds by ring depth (one / two / three or more waves per SIMD): 63 000 and 105 000
+    # lanes take the other two; the arithmetic is the same instruction sequence, so the values are bit-identical
+    for npairs in (900, 1500):
+        v = gpu.like(many[:npairs], big[:npairs])
+        assert gpu.last_chunks()[0] == 1
+        assert np.array_equal(v, bvals[:npairs])
     perm = np.random.default_rng(1).permutation(len(many))[:500]
     c = gpu.like(many[perm], big[perm][:, :2])
     # 1000 lanes take the SNP-chunked route, 420k lanes the single sweep: equal to rounding, not bit for bit
