@@ -4,7 +4,7 @@
 // with per-lane parameters is not a dense contraction).
 //
 // Numerics.  The reference walks the SNPs in log space (3 exp + 6 log per step).  Here the recursion runs in the
-// linear domain and is renormalised by exact powers of two every 8 steps; the exponent is accumulated as an
+// linear domain and is renormalised by exact powers of two every 16 steps; the exponent is accumulated as an
 // integer and one log is taken at the end.  The two exponentials per step (e^{-a t}, e^{-a k1 t}; a is per lane,
 // t per SNP) are inherent; they enter only through expm1, because the transition matrix is affine in
 // (e1 - 1, e2 - 1) with NO constant term off the diagonal:
@@ -304,12 +304,18 @@ __device__ inline void sweep(const EmisRec *__restrict__ rec, int RP, int lp, in
       rec + lp, (size_t)RP, sb, se, M,
       [&](const EmisRec(&R)[kGroup], int s) {
         fwd_group<NV, DR>(C, R, x);
-        if (s & kGroup) {  // every second group: 8 steps between renormalisations
+        if ((s & 12) == 12) {  // every fourth group: 16 steps between renormalisations (emissions >= ~1e-8 each)
 #pragma unroll
           for (int v = 0; v < NV; v++) ex[v] += rescale3(x[v][0], x[v][1], x[v][2]);
         }
       },
-      [&](const EmisRec &r, int) { fwd_step<NV, DR, 2>(C, r, x); });
+      [&](const EmisRec &r, int s) {
+        fwd_step<NV, DR, 2>(C, r, x);
+        if ((s & 7) == 7) {  // the tail can be NBUF * kGroup - 1 records long
+#pragma unroll
+          for (int v = 0; v < NV; v++) ex[v] += rescale3(x[v][0], x[v][1], x[v][2]);
+        }
+      });
 #pragma unroll
   for (int v = 0; v < NV; v++) ex[v] += rescale3(x[v][0], x[v][1], x[v][2]);
 }
