@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the hot path: the same stage + like + decode step as bench.py, but through the host-buffer
+entry points (relate_hip_like / relate_hip_decode), i.e. with the parameter upload and the posterior copy-back."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench, relate_amd
+from relate_amd import synth
+P, E, N, M = 512, 5, 2000, 500000
+opt = bench.opts_all_pair(); opt["back2"] = 2 * opt["back"]
+geno, pos, chr_, _ = synth.make_dataset(N, M, device="cuda:0")
+H = relate_amd.Relate(0)
+M = H.init_globals(geno, pos, chr_, opt)
+allp = synth.all_pairs(N)
+par = bench.eval_points(P, E)
+for it in range(3):
+    blk = allp[it * P:(it + 1) * P]
+    t0 = time.perf_counter()
+    H.like(blk, par)
+    post, _, _ = H.decode(blk, np.ascontiguousarray(par[:, 0, :]))
+    dt = time.perf_counter() - t0
+    print("P=%d M=%d: %.1f ms per step with host buffers = %.3g HMM steps/s (posterior copy-back %.2f GB)" % (
+        P, M, dt * 1e3, P * M * (E + 2) / dt, post.nbytes / 1e9), flush=True)
