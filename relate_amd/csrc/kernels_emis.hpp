@@ -386,7 +386,7 @@ stage_pairs_win_kernel(const uint64_t *__restrict__ Gt, int M, int Wt, const int
     int kmax = min(32, M - w * 32);
     // Batches of kBatch SNPs: first all selections (register work) and the position loads, then all table loads, then
     // all stores, so that a lane has kBatch gathers in flight instead of one memory round trip per SNP.
-    constexpr int kBatch = 8;
+    constexpr int kBatch = 4;
     for (int k0 = 0; k0 < kmax; k0 += kBatch) {
       const double *e[kBatch];
       double tpos[kBatch], lpos[kBatch];
