@@ -375,21 +375,37 @@ chunk_matrix_kernel(const EmisRec *__restrict__ rec, int M, int RP, const int32_
   }
 }
 
+// one chunk product in registers; the combine kernels load the next one while they fold the current one (their loops
+// are serial per lane and latency-bound: one strided load round trip per chunk otherwise)
+struct ChunkProd {
+  double m[9];
+  int e[3];
+};
+__device__ inline ChunkProd load_chunk(const ChunkOut &O, size_t n, size_t at) {
+  ChunkProd X;
+#pragma unroll
+  for (int i = 0; i < 9; i++) X.m[i] = O.m[(size_t)i * n + at];
+#pragma unroll
+  for (int i = 0; i < 3; i++) X.e[i] = O.e[(size_t)i * n + at];
+  return X;
+}
+
 // alpha <- alpha * (chunk product); returns the exponent moved out
-__device__ inline int apply_chunk_fwd(double &f0, double &f1, double &f2, const ChunkOut &O, size_t n, size_t at) {
+__device__ inline int apply_chunk_fwd(double &f0, double &f1, double &f2, const ChunkProd &X) {
   double a[3] = {f0, f1, f2};
-  int e[3] = {O.e[at], O.e[n + at], O.e[2 * n + at]};
   int emax = -2147483647;
+#pragma unroll
   for (int i = 0; i < 3; i++)
-    if (a[i] > 0 && e[i] > emax) emax = e[i];
+    if (a[i] > 0 && X.e[i] > emax) emax = X.e[i];
   if (emax == -2147483647) { f0 = f1 = f2 = 0; return 0; }
   double r0 = 0, r1 = 0, r2 = 0;
+#pragma unroll
   for (int i = 0; i < 3; i++) {
     if (!(a[i] > 0)) continue;
-    double w = ldexp(a[i], e[i] - emax);
-    r0 += w * O.m[(size_t)(i * 3 + 0) * n + at];
-    r1 += w * O.m[(size_t)(i * 3 + 1) * n + at];
-    r2 += w * O.m[(size_t)(i * 3 + 2) * n + at];
+    double w = ldexp(a[i], X.e[i] - emax);
+    r0 += w * X.m[i * 3 + 0];
+    r1 += w * X.m[i * 3 + 1];
+    r2 += w * X.m[i * 3 + 2];
   }
   f0 = r0; f1 = r1; f2 = r2;
   return emax;
@@ -406,10 +422,12 @@ like_combine_kernel(ChunkOut O, const double *__restrict__ params, int nlanes, i
   size_t n = (size_t)nlp * nchunk;
   double f0 = k0, f1 = k1, f2 = k2;
   long esum = 0;
+  ChunkProd X = load_chunk(O, n, (size_t)l);
   for (int c = 0; c < nchunk; c++) {
-    size_t at = (size_t)c * nlp + l;
-    esum += apply_chunk_fwd(f0, f1, f2, O, n, at);
+    ChunkProd Xn = load_chunk(O, n, (size_t)min(c + 1, nchunk - 1) * nlp + l);
+    esum += apply_chunk_fwd(f0, f1, f2, X);
     esum += rescale3(f0, f1, f2);
+    X = Xn;
   }
   double tot = (f0 + f1) + f2;
   out[l] = -(log(tot) + (double)esum * kLn2);
@@ -434,30 +452,36 @@ decode_combine_kernel(ChunkOut O, const double *__restrict__ params, int P, int 
   double k2 = params[3 * p + 1], k1 = params[3 * p + 2];
   double k0 = 1 - k2 - k1;  // decodek2, :1018
   double f0 = k0, f1 = k1, f2 = k2;
+  ChunkProd X = load_chunk(O, n, (size_t)p);
   for (int c = 0; c < nchunk; c++) {
     size_t at = (size_t)c * nlp + p;
+    ChunkProd Xn = load_chunk(O, n, (size_t)min(c + 1, nchunk - 1) * nlp + p);
     astart[at * 3] = f0; astart[at * 3 + 1] = f1; astart[at * 3 + 2] = f2;
-    apply_chunk_fwd(f0, f1, f2, O, n, at);
+    apply_chunk_fwd(f0, f1, f2, X);
     norm_fast(f0, f1, f2);
+    X = Xn;
   }
   double b0 = 1, b1 = 1, b2 = 1;
+  X = load_chunk(O, n, (size_t)(nchunk - 1) * nlp + p);
   for (int c = nchunk - 1; c >= 0; c--) {
     size_t at = (size_t)c * nlp + p;
+    ChunkProd Xn = load_chunk(O, n, (size_t)max(c - 1, 0) * nlp + p);
     bend[at * 3] = b0; bend[at * 3 + 1] = b1; bend[at * 3 + 2] = b2;
     // beta_start[i] = 2^{e[i]} sum_y X[i][y] beta[y]
     double v[3];
-    int e[3], emax = -2147483647;
+    int emax = -2147483647;
+#pragma unroll
     for (int i = 0; i < 3; i++) {
-      v[i] = O.m[(size_t)(i * 3 + 0) * n + at] * b0 + O.m[(size_t)(i * 3 + 1) * n + at] * b1 +
-             O.m[(size_t)(i * 3 + 2) * n + at] * b2;
-      e[i] = O.e[(size_t)i * n + at];
-      if (v[i] > 0 && e[i] > emax) emax = e[i];
+      v[i] = X.m[i * 3 + 0] * b0 + X.m[i * 3 + 1] * b1 + X.m[i * 3 + 2] * b2;
+      if (v[i] > 0 && X.e[i] > emax) emax = X.e[i];
     }
-    if (emax == -2147483647) continue;
-    b0 = v[0] > 0 ? ldexp(v[0], e[0] - emax) : 0;
-    b1 = v[1] > 0 ? ldexp(v[1], e[1] - emax) : 0;
-    b2 = v[2] > 0 ? ldexp(v[2], e[2] - emax) : 0;
-    norm_fast(b0, b1, b2);
+    if (emax != -2147483647) {
+      b0 = v[0] > 0 ? ldexp(v[0], X.e[0] - emax) : 0;
+      b1 = v[1] > 0 ? ldexp(v[1], X.e[1] - emax) : 0;
+      b2 = v[2] > 0 ? ldexp(v[2], X.e[2] - emax) : 0;
+      norm_fast(b0, b1, b2);
+    }
+    X = Xn;
   }
 }
 
