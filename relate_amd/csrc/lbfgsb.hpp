@@ -57,13 +57,13 @@ class Lbfgsb {
   double theta_, fold_, tol_, dnorm_, epsmch_, gd_, stpmx_, sbgnrm_, stp_, gdold_, dtd_;
   bool wrk_ = false;
   // dcsrch state
-  bool ls_start_ = true, brackt_;
+  bool brackt_;
   int stage_;
   double ginit_, gtest_, gx_, gy_, finit_, fx_, fy_, stx_, sty_, stmin_, stmax_, width_, width1_;
   enum LsTask { LS_START, LS_FG, LS_CONV, LS_WARN, LS_ERROR } lstask_ = LS_START;
 
   std::vector<double> ws_, wy_, sy_, ss_, wt_, wn_, snd_;
-  double z_[kMaxN + 1], r_[kMaxN + 1], d_[kMaxN + 1], t_[kMaxN + 1], xs_[kMaxN + 1], gs_[kMaxN + 1];
+  double z_[kMaxN + 1], r_[kMaxN + 1], d_[kMaxN + 1], t_[kMaxN + 1], xs_[kMaxN + 1];
   double wa_[8 * kM + 1];
   int index_[kMaxN + 1], iwhere_[kMaxN + 1], indx2_[kMaxN + 1];
 
