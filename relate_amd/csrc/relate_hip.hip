@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -45,6 +46,44 @@ struct DBuf {  // grow-only device buffer
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
+  }
+};
+
+// Pinned host buffers of one pair population (grow-only) and the events of its launch in flight.
+struct LaneBufs {
+  int32_t *lane = nullptr;
+  double *par = nullptr, *val = nullptr;
+  size_t cap = 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr, done = nullptr;
+  int nl = 0, chunks = 1;
+  hipError_t ensure(size_t n) {
+    if (!e0) {
+      hipError_t e = hipEventCreate(&e0);
+      if (e == hipSuccess) e = hipEventCreate(&e1);
+      if (e == hipSuccess) e = hipEventCreate(&done);
+      if (e != hipSuccess) return e;
+    }
+    if (n <= cap) return hipSuccess;
+    release_mem();
+    size_t c = std::max<size_t>(n + n / 4, 4096);
+    hipError_t e = hipHostMalloc((void **)&lane, c * sizeof(int32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&par, 3 * c * sizeof(double));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&val, c * sizeof(double));
+    if (e == hipSuccess) cap = c;
+    return e;
+  }
+  void release_mem() {
+    if (lane) (void)hipHostFree(lane);
+    if (par) (void)hipHostFree(par);
+    if (val) (void)hipHostFree(val);
+    lane = nullptr; par = val = nullptr; cap = 0;
+  }
+  void release() {
+    release_mem();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (done) (void)hipEventDestroy(done);
+    e0 = e1 = done = nullptr;
   }
 };
 
@@ -89,6 +128,7 @@ struct relate_hip_ctx {
   DBuf<int> dNsnp;
   DBuf<double> dCm, dAstart, dBend;  // chunk products and boundary vectors of the chunked sweeps
   DBuf<int> dCe;
+  LaneBufs lanebufs[2];  // pinned lane buffers of the two pair populations of a fit
   double timings[4] = {0, 0, 0, 0};
   int last_chunks[2] = {1, 1};  // SNP-axis chunks of the last like / decode launch
   long slots_like = 2048, slots_decode = 6144;  // resident waves of the chunked sweeps (set at create)
@@ -221,7 +261,8 @@ int stage_block(relate_hip_t h, const int32_t *pairs, int P) {
 // Launches with at least this many lanes run as one sweep per lane; fewer are cut along the SNP axis.  Measured
 // crossover (M = 1e5): a lone wave per SIMD walks its chain in 10.4 ms whatever the lane count, the chunked path
 // sustains ~420 G lane-steps/s, equal at ~44 000 lanes.  RELATE_SINGLE_SWEEP_LANES overrides (tuning experiments).
-long g_single_sweep_lanes = 45056;
+constexpr long kSingleSweepLanesDefault = 45056;
+long g_single_sweep_lanes = kSingleSweepLanesDefault;
 
 void pick_chunks(int M, long lanes, int wg_threads, long slots, int rounds, int *nchunk, int *chunk_len) {
   long c = 1;
@@ -337,27 +378,286 @@ int require_ready(relate_hip_t h) {
   return set_device(h);
 }
 
-// batched run_optimization for the staged block (P pairs): fills out[] and conv_out
+// ---- batched run_optimization for the staged block ---------------------------------------------------------------
+// K5 for the lanes in B (pinned), queued on the library's stream without waiting: upload, kernels, download, event.
+// The device lane buffers are shared by the populations; stream order keeps one launch's use of them apart from the
+// next one's upload.
+int like_enqueue(relate_hip_t h, int P, LaneBufs &B) {
+  const int nl = B.nl;
+  HIPCHK(h, h->dLanePair.ensure(nl));
+  HIPCHK(h, h->dParams.ensure((size_t)3 * nl));
+  HIPCHK(h, h->dOut.ensure(nl));
+  HIPCHK(h, hipMemcpyAsync(h->dLanePair.p, B.lane, sizeof(int32_t) * nl, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->dParams.p, B.par, sizeof(double) * 3 * nl, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipEventRecord(B.e0, h->stream));
+  int rc = launch_like(h, P, nl);
+  if (rc) return rc;
+  B.chunks = h->last_chunks[0];
+  HIPCHK(h, hipEventRecord(B.e1, h->stream));
+  HIPCHK(h, hipMemcpyAsync(B.val, h->dOut.p, sizeof(double) * nl, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipEventRecord(B.done, h->stream));
+  return 0;
+}
+int like_wait(relate_hip_t h, LaneBufs &B) {
+  HIPCHK(h, hipEventSynchronize(B.done));
+  float ms = 0;
+  HIPCHK(h, hipEventElapsedTime(&ms, B.e0, B.e1));
+  h->timings[1] += ms;
+  if (getenv("RELATE_FIT_TRACE"))
+    std::fprintf(stderr, "like launch: %d lanes, %d chunks, %.3f ms\n", B.nl, B.chunks, ms);
+  return 0;
+}
+
+// One population of pairs of the staged block with its optimiser state: prepare() advances the multi-start rule,
+// starts and retires runs and lays out the lanes of the next likelihood launch; consume() feeds the values back.
+struct FitPop {
+  struct Run {
+    FindMax fm;
+    int pair, idx;          // pair = index inside the population
+    int slot[7];            // for each requested point: lane index, or -1 if the wrapper short-circuits
+    size_t lane0 = 0;       // first lane of this run in the launch
+    bool waited = false;    // its request was held back in the previous round
+    bool taken = true;      // its request is part of this round's launch
+    double akk[7][3];       // the request mapped to (a, k2, k1)
+    bool ok[7];
+    int nlanes = 0;
+    bool bad = false;
+  };
+  int p0 = 0, P = 0;  // pairs [p0, p0 + P) of the staged block
+  const relate_opts *o = nullptr;
+  FitSpec S{};
+  int n = 0, R = 1;
+  double lo[3], hi[3];
+  const double *starts = nullptr;
+  long pair_base = 0;
+  std::vector<MultiStart> ms;
+  std::vector<GlibcRand> rng;
+  std::vector<std::vector<double>> results;
+  std::vector<std::vector<char>> have;
+  std::vector<Run *> active;
+  bool first_round = true, inflight = false, finished = false;
+  LaneBufs *B = nullptr;
+
+  ~FitPop() {
+    for (Run *r : active) delete r;
+  }
+  void init(int p0_, int P_, const relate_opts *o_, const FitSpec &S_, const double *starts_, long pair_base_,
+            LaneBufs *B_) {
+    p0 = p0_; P = P_; o = o_; S = S_; starts = starts_; pair_base = pair_base_; B = B_;
+    n = S.nvar();
+    R = std::max(1, o->timesToRun);
+    mode_bounds(S, lo, hi);
+    ms.assign(P, MultiStart());
+    for (int p = 0; p < P; p++) {
+      ms[p].timesToConverge = o->timesToConverge;
+      ms[p].timesToRun = R;
+      ms[p].convTol = o->convTol;
+    }
+    if (!starts) {
+      rng.reserve(P);
+      for (int p = 0; p < P; p++)
+        rng.emplace_back(o->seed_mode == 1 ? o->seed + (unsigned)(pair_base + p0 + p) : o->seed);
+    }
+    results.assign(P, std::vector<double>((size_t)R * 4, 0.0));
+    have.assign(P, std::vector<char>(R, 0));
+  }
+
+  // returns the number of lanes laid out in B, or -1 on a pinned-memory error; sets `finished` when no run is left.
+  // Zero lanes with runs left is possible: every requested point short-circuits in its wrapper (infeasible k).
+  long prepare() {
+    auto by_pair = [](const Run *x, const Run *y) { return x->pair != y->pair ? x->pair < y->pair : x->idx < y->idx; };
+    for (;;) {
+      // `active` stays sorted by (pair, restart): lanes of one pair side by side read the same records, so a wave
+      // touches ~13 distinct records per step instead of 64 (measured 250 -> 330 G lane-steps/s on the chunked
+      // path).  New runs arrive in that order at the tail and are merged in; retired runs are removed in place.
+      const size_t n_before = active.size();
+      for (int p = 0; p < P; p++) {
+        int w = ms[p].want_to_launch();
+        for (int q = 0; q < w; q++) {
+          Run *r = new Run();
+          r->pair = p;
+          r->idx = ms[p].launched++;
+          double st[4], x0[3];
+          if (starts) std::memcpy(st, starts + ((size_t)(pair_base + p0 + p) * R + r->idx) * 4, sizeof(st));
+          else draw_start(rng[p], S, o->fixK, st);
+          start_to_x(S, st, x0);
+          r->fm.begin(n, x0, lo, hi);
+          active.push_back(r);
+        }
+      }
+      if (n_before > 0 && active.size() > n_before)
+        std::inplace_merge(active.begin(), active.begin() + n_before, active.end(), by_pair);
+      // retire finished runs, feed the multi-start rule in index order
+      bool relaunch = false;
+      for (bool progressed = true; progressed && !relaunch;) {
+        progressed = false;
+        size_t keep_n = 0;
+        for (size_t i = 0; i < active.size(); i++) {
+          Run *r = active[i];
+          if (r->fm.done) {
+            x_to_result(S, r->fm.opt.x, r->fm.like, &results[r->pair][(size_t)r->idx * 4]);
+            have[r->pair][r->idx] = 1;
+            delete r;
+            progressed = true;
+          } else
+            active[keep_n++] = r;
+        }
+        active.resize(keep_n);
+        for (int p = 0; p < P; p++)
+          while (!ms[p].finished && ms[p].consumed < ms[p].launched && have[p][ms[p].consumed])
+            ms[p].consume(&results[p][(size_t)ms[p].consumed * 4]);
+        // runs started ahead of need for a pair whose rule has stopped meanwhile are dropped unseen
+        keep_n = 0;
+        for (size_t i = 0; i < active.size(); i++) {
+          if (ms[active[i]->pair].finished) delete active[i];
+          else active[keep_n++] = active[i];
+        }
+        active.resize(keep_n);
+        for (int p = 0; p < P && !relaunch; p++)
+          if (ms[p].want_to_launch() > 0) relaunch = true;
+      }
+      if (relaunch) continue;
+      break;
+    }
+    if (active.empty() && !first_round) {
+      finished = true;
+      return 0;
+    }
+    // Whole turns of the machine.  A single sweep costs the time of its fullest SIMD: 100 000 steps take 10.4 ms
+    // with up to one wave per SIMD (65 536 lanes), 17.5 ms with up to two, 26 ms with up to three, so 70 000 lanes
+    // cost as much as 131 072.  A round with more than one full turn of requests launches whole turns only and
+    // holds the rest back one round (runs are independent state machines; a held request is simply answered later,
+    // with the same values).  Held runs go first in the next round, so none waits twice.
+    const long kTurn = 256L * 4 * 64;
+    parallel_for(active.size(), [&](size_t lo_, size_t hi_) {
+      for (size_t i = lo_; i < hi_; i++) {  // lanes a run needs: the points its wrapper does not short-circuit
+        Run *r = active[i];
+        r->nlanes = 0;
+        for (int q = 0; q < r->fm.npts; q++) {
+          r->ok[q] = map_point(S, r->fm.pts[q], r->akk[q]);
+          r->nlanes += r->ok[q] ? 1 : 0;
+        }
+      }
+    });
+    long want = 0;
+    for (Run *r : active) want += r->nlanes;
+    long budget = (!first_round && want > kTurn) ? (want / kTurn) * kTurn : want;
+    long used = 0;
+    for (Run *r : active) {
+      r->taken = r->waited;
+      if (r->taken) used += r->nlanes;
+    }
+    for (Run *r : active) {
+      if (r->taken) continue;
+      if (used + r->nlanes <= budget) {
+        r->taken = true;
+        used += r->nlanes;
+      }
+    }
+    // uLike / poLike (:3478-3481) ride along with the first launch: lanes 2p, 2p+1
+    size_t nl_total = first_round ? (size_t)2 * P : 0;
+    for (Run *r : active) {
+      r->waited = !r->taken;
+      r->lane0 = nl_total;
+      if (r->taken) nl_total += r->nlanes;
+    }
+    if (B->ensure(nl_total) != hipSuccess) return -1;
+    B->nl = (int)nl_total;
+    if (first_round)
+      for (int p = 0; p < P; p++)
+        for (int j = 0; j < 2; j++) {
+          size_t at = (size_t)2 * p + j;
+          B->lane[at] = p0 + p;
+          B->par[3 * at] = o->alim[0]; B->par[3 * at + 1] = 0; B->par[3 * at + 2] = j;
+        }
+    parallel_for(active.size(), [&](size_t lo_, size_t hi_) {
+      for (size_t i = lo_; i < hi_; i++) {
+        Run *r = active[i];
+        if (!r->taken) continue;
+        size_t at = r->lane0;
+        for (int q = 0; q < r->fm.npts; q++) {
+          r->slot[q] = -1;
+          if (r->ok[q]) {
+            r->slot[q] = (int)at;
+            B->lane[at] = p0 + r->pair;
+            B->par[3 * at] = r->akk[q][0]; B->par[3 * at + 1] = r->akk[q][1]; B->par[3 * at + 2] = r->akk[q][2];
+            at++;
+          }
+        }
+      }
+    });
+    return (long)nl_total;
+  }
+
+  void consume(relate_fit *out) {  // out: records of the staged block
+    const double *val = B->val;
+    if (first_round) {
+      for (int p = 0; p < P; p++) {
+        out[p0 + p].uLike = val[2 * p];
+        out[p0 + p].poLike = val[2 * p + 1];
+      }
+      first_round = false;
+    }
+    parallel_for(active.size(), [&](size_t lo_, size_t hi_) {
+      for (size_t i = lo_; i < hi_; i++) {
+        Run *r = active[i];
+        if (!r->taken) continue;
+        double v[7];
+        bool bad = false;
+        for (int q = 0; q < r->fm.npts; q++) {
+          v[q] = r->slot[q] < 0 ? kSysMax : val[r->slot[q]];
+          if (!std::isfinite(v[q])) bad = true;
+        }
+        if (bad) {  // the reference prints and exit(0)s on NaN (:1513-1520); flag the pair and stop this run
+          r->bad = true;
+          r->fm.done = true;
+          r->fm.like = NAN;
+          continue;
+        }
+        r->fm.supply(v);
+      }
+    });
+    for (Run *r : active)
+      if (r->bad) out[p0 + r->pair].status = RELATE_E_NUMERIC;
+  }
+
+  void finish(relate_fit *out, double *conv_out) {
+    for (int p = 0; p < P; p++) {
+      relate_fit &f = out[p0 + p];
+      f.a = ms[p].best[0];
+      f.k2 = ms[p].best[1];
+      f.k1 = ms[p].best[2];
+      f.k0 = 1 - f.k2 - f.k1;
+      f.negloglik = ms[p].best[3];
+      f.timesRun = ms[p].consumed;
+      f.timesConverged = ms[p].conv;
+      if (conv_out)  // convInfo: the runs the rule consumed; rows beyond stay zero (speculative runs are not reported)
+        std::memcpy(conv_out + (size_t)(pair_base + p0 + p) * R * 4, results[p].data(),
+                    sizeof(double) * ms[p].consumed * 4);
+    }
+  }
+};
+
+// fills out[0..P) (and conv_out rows pair_base..) for the P pairs of the staged block
 int fit_block(relate_hip_t h, int P, const int32_t *pairs, long pair_base, const double *starts, relate_fit *out,
               double *conv_out) {
+  (void)pairs;
   const relate_opts &o = h->o;
-  const int R = std::max(1, o.timesToRun);
   for (int p = 0; p < P; p++) {
     out[p] = relate_fit{};
     out[p].status = 0;
   }
-  // uLike / poLike (:3478-3481) ride along with the first launch
-  std::vector<int32_t> lp;
-  std::vector<double> par, val;
-  auto push = [&](int p, double a, double k2, double k1) {
-    lp.push_back(p);
-    par.push_back(a); par.push_back(k2); par.push_back(k1);
-  };
-  for (int p = 0; p < P; p++) {
-    push(p, o.alim[0], 0, 0);
-    push(p, o.alim[0], 0, 1);
-  }
-  if (o.doPar) {
+  if (o.doPar) {  // likelihood at the user's parameters, no optimisation (:3484-3510)
+    std::vector<int32_t> lp;
+    std::vector<double> par, val;
+    auto push = [&](int p, double a, double k2, double k1) {
+      lp.push_back(p);
+      par.push_back(a); par.push_back(k2); par.push_back(k1);
+    };
+    for (int p = 0; p < P; p++) {
+      push(p, o.alim[0], 0, 0);
+      push(p, o.alim[0], 0, 1);
+    }
     for (int p = 0; p < P; p++) push(p, o.par[0], o.par[1], o.par[2]);
     val.resize(lp.size());
     int rc = like_lanes(h, P, lp.data(), par.data(), (int)lp.size(), val.data());
@@ -379,187 +679,51 @@ int fit_block(relate_hip_t h, int P, const int32_t *pairs, long pair_base, const
                 "optimization not implemented for this fixA/fixK/calcA combination (the reference exits, "
                 "src/relateHMM.cpp:1898-1901; fixA without fixK is undefined there)");
   FitSpec S{mode, o.fixA_val, o.fixK_val, o.phi, o.alim[0], o.alim[1]};
-  const int n = S.nvar();
-  double lo[3], hi[3];
-  mode_bounds(S, lo, hi);
-
-  struct Run {
-    FindMax fm;
-    int pair, idx;
-    std::vector<int> slot;  // for each requested point: index into val, or -1 if the wrapper short-circuits
-    bool waited = false;    // its request was held back in the previous round
-    bool taken = true;      // its request is part of this round's launch
-    double akk[7][3];       // the request mapped to (a, k2, k1)
-    bool ok[7];
-    int nlanes = 0;
-    bool bad = false;
+  // Two populations of pairs take turns on the GPU: while the likelihood launch of one runs, the host retires runs,
+  // steps the optimisers and lays out the next launch of the other (pinned buffers, events; nothing waits on the
+  // stream as a whole).  Pairs are independent, so the split changes no value.  Small blocks stay one population.
+  // Each population should still fill whole turns of the machine on its own (a few runs of 3-5 lanes per pair), or the
+  // split costs more likelihood time than the overlap saves: 8 192 pairs x 5e5 SNPs ran 13.0 s unsplit, 15.6 s split;
+  // 44 850 pairs x 5e4 SNPs 15.6 s unsplit, 9.7 s split.  RELATE_FIT_POPULATIONS = 1 | 2 overrides (tests, tuning).
+  int npop = P >= 16384 ? 2 : 1;
+  if (const char *e = getenv("RELATE_FIT_POPULATIONS")) npop = atoi(e) >= 2 && P >= 2 ? 2 : 1;
+  FitPop pop[2];
+  for (int k = 0; k < npop; k++) {
+    int b = (int)((long)P * k / npop), e = (int)((long)P * (k + 1) / npop);
+    pop[k].init(b, e - b, &o, S, starts, pair_base, &h->lanebufs[k]);
+  }
+  auto start = [&](FitPop &F) -> int {
+    F.inflight = false;
+    for (;;) {
+      long nl = F.prepare();
+      if (nl < 0) return fail(h, RELATE_E_NOMEM, "pinned host memory for the likelihood lanes");
+      if (F.finished) return 0;
+      if (nl > 0) {
+        F.inflight = true;
+        return like_enqueue(h, P, *F.B);
+      }
+      F.consume(out);  // nothing to evaluate on the GPU this round: the wrappers answered every point themselves
+    }
   };
-  std::vector<MultiStart> ms(P);
-  std::vector<GlibcRand> rng;
-  if (!starts) {
-    rng.reserve(P);
-    for (int p = 0; p < P; p++)
-      rng.emplace_back(o.seed_mode == 1 ? o.seed + (unsigned)(pair_base + p) : o.seed);
+  int rc = 0;
+  for (int k = 0; k < npop && !rc; k++) rc = start(pop[k]);
+  for (bool any = true; any && !rc;) {
+    any = false;
+    for (int k = 0; k < npop && !rc; k++) {
+      FitPop &F = pop[k];
+      if (!F.inflight) continue;
+      any = true;
+      rc = like_wait(h, *F.B);
+      if (rc) break;
+      F.consume(out);
+      rc = start(F);
+    }
   }
-  std::vector<std::vector<double>> results(P, std::vector<double>((size_t)R * 4, 0.0));
-  std::vector<std::vector<char>> have(P, std::vector<char>(R, 0));
-  std::vector<Run *> active;
-  for (int p = 0; p < P; p++) {
-    ms[p].timesToConverge = o.timesToConverge;
-    ms[p].timesToRun = R;
-    ms[p].convTol = o.convTol;
+  if (rc) {
+    (void)hipStreamSynchronize(h->stream);  // nothing of a failed block stays queued on its buffers
+    return rc;
   }
-  bool first_round = true;
-  for (;;) {
-    // launch the runs each pair wants
-    for (int p = 0; p < P; p++) {
-      int w = ms[p].want_to_launch();
-      for (int q = 0; q < w; q++) {
-        Run *r = new Run();
-        r->pair = p;
-        r->idx = ms[p].launched++;
-        double st[4], x0[3];
-        if (starts) std::memcpy(st, starts + ((size_t)(pair_base + p) * R + r->idx) * 4, sizeof(st));
-        else draw_start(rng[p], S, o.fixK, st);
-        start_to_x(S, st, x0);
-        r->fm.begin(n, x0, lo, hi);
-        active.push_back(r);
-      }
-    }
-    // retire finished runs, feed the multi-start rule in index order
-    bool progressed = true;
-    while (progressed) {
-      progressed = false;
-      for (size_t i = 0; i < active.size();) {
-        Run *r = active[i];
-        if (r->fm.done) {
-          x_to_result(S, r->fm.opt.x, r->fm.like, &results[r->pair][(size_t)r->idx * 4]);
-          have[r->pair][r->idx] = 1;
-          delete r;
-          active[i] = active.back();
-          active.pop_back();
-          progressed = true;
-        } else
-          i++;
-      }
-      for (int p = 0; p < P; p++)
-        while (!ms[p].finished && ms[p].consumed < ms[p].launched && have[p][ms[p].consumed])
-          ms[p].consume(&results[p][(size_t)ms[p].consumed * 4]);
-      // runs started ahead of need for a pair whose rule has stopped meanwhile are dropped unseen
-      for (size_t i = 0; i < active.size();) {
-        if (ms[active[i]->pair].finished) {
-          delete active[i];
-          active[i] = active.back();
-          active.pop_back();
-        } else
-          i++;
-      }
-      bool relaunch = false;
-      for (int p = 0; p < P; p++)
-        if (ms[p].want_to_launch() > 0) relaunch = true;
-      if (relaunch) break;
-    }
-    bool any_want = false;
-    for (int p = 0; p < P; p++)
-      if (ms[p].want_to_launch() > 0) any_want = true;
-    if (any_want) continue;
-    if (active.empty() && !first_round) break;
-    // gather the requested points of every active run into one launch
-    if (!first_round) { lp.clear(); par.clear(); }
-    // lanes of one pair side by side: they read the same records, so a wave touches ~13 distinct records per step
-    // instead of 64 (retiring runs swaps the list around; measured 250 -> 330 G lane-steps/s on the chunked path)
-    std::sort(active.begin(), active.end(), [](const Run *x, const Run *y) {
-      return x->pair != y->pair ? x->pair < y->pair : x->idx < y->idx;
-    });
-    // Whole turns of the machine.  A single sweep costs the time of its fullest SIMD: 100 000 steps take 10.4 ms
-    // with up to one wave per SIMD (65 536 lanes), 17.5 ms with up to two, 26 ms with up to three, so 70 000 lanes
-    // cost as much as 131 072.  A round with more than one full turn of requests launches whole turns only and
-    // holds the rest back one round (runs are independent state machines; a held request is simply answered later,
-    // with the same values).  Held runs go first in the next round, so none waits twice.
-    const long kTurn = 256L * 4 * 64;
-    long want = 0;
-    parallel_for(active.size(), [&](size_t lo_, size_t hi_) {
-      for (size_t i = lo_; i < hi_; i++) {  // lanes a run needs: the points its wrapper does not short-circuit
-        Run *r = active[i];
-        r->nlanes = 0;
-        for (int q = 0; q < r->fm.npts; q++) {
-          r->ok[q] = map_point(S, r->fm.pts[q], r->akk[q]);
-          r->nlanes += r->ok[q] ? 1 : 0;
-        }
-      }
-    });
-    for (Run *r : active) want += r->nlanes;
-    long budget = (!first_round && want > kTurn) ? (want / kTurn) * kTurn : want;
-    long used = 0;
-    for (Run *r : active) {
-      r->taken = r->waited;
-      if (r->taken) used += r->nlanes;
-    }
-    for (Run *r : active) {
-      if (r->taken) continue;
-      if (used + r->nlanes <= budget) {
-        r->taken = true;
-        used += r->nlanes;
-      }
-    }
-    for (Run *r : active) {
-      r->waited = !r->taken;
-      if (!r->taken) continue;
-      r->slot.assign(r->fm.npts, -1);
-      for (int q = 0; q < r->fm.npts; q++) {
-        if (r->ok[q]) {
-          r->slot[q] = (int)lp.size();
-          push(r->pair, r->akk[q][0], r->akk[q][1], r->akk[q][2]);
-        }
-      }
-    }
-    val.resize(lp.size());
-    int rc = like_lanes(h, P, lp.data(), par.data(), (int)lp.size(), val.data());
-    if (rc) {
-      for (Run *r : active) delete r;
-      return rc;
-    }
-    if (first_round) {
-      for (int p = 0; p < P; p++) {
-        out[p].uLike = val[2 * p];
-        out[p].poLike = val[2 * p + 1];
-      }
-      first_round = false;
-    }
-    parallel_for(active.size(), [&](size_t lo_, size_t hi_) {
-      for (size_t i = lo_; i < hi_; i++) {
-        Run *r = active[i];
-        if (!r->taken) continue;
-        double v[7];
-        for (int q = 0; q < r->fm.npts; q++) v[q] = r->slot[q] < 0 ? kSysMax : val[r->slot[q]];
-        bool bad = false;
-        for (int q = 0; q < r->fm.npts; q++)
-          if (!std::isfinite(v[q])) bad = true;
-        if (bad) {  // the reference prints and exit(0)s on NaN (:1513-1520); flag the pair and stop this run
-          r->bad = true;
-          r->fm.done = true;
-          r->fm.like = NAN;
-          continue;
-        }
-        r->fm.supply(v);
-      }
-    });
-    for (Run *r : active)
-      if (r->bad) out[r->pair].status = RELATE_E_NUMERIC;
-    if (active.empty()) break;
-  }
-  for (int p = 0; p < P; p++) {
-    out[p].a = ms[p].best[0];
-    out[p].k2 = ms[p].best[1];
-    out[p].k1 = ms[p].best[2];
-    out[p].k0 = 1 - out[p].k2 - out[p].k1;
-    out[p].negloglik = ms[p].best[3];
-    out[p].timesRun = ms[p].consumed;
-    out[p].timesConverged = ms[p].conv;
-    if (conv_out)  // convInfo: the runs the rule consumed; rows beyond stay zero (speculative runs are not reported)
-      std::memcpy(conv_out + (size_t)(pair_base + p) * R * 4, results[p].data(), sizeof(double) * ms[p].consumed * 4);
-  }
-  (void)pairs;
+  for (int k = 0; k < npop; k++) pop[k].finish(out, conv_out);
   return 0;
 }
 
@@ -665,7 +829,10 @@ int relate_hip_create(relate_hip_t *out, int device_id) {
                 std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
                     " (librelate_hip has no CPU fallback)");
   if (device_id < 0 || device_id >= ndev) return fail(nullptr, RELATE_E_ARG, "device_id out of range");
-  if (const char *e = getenv("RELATE_SINGLE_SWEEP_LANES")) g_single_sweep_lanes = atol(e);
+  {
+    const char *e = getenv("RELATE_SINGLE_SWEEP_LANES");
+    g_single_sweep_lanes = e ? atol(e) : kSingleSweepLanesDefault;
+  }
   relate_hip_ctx *h = new relate_hip_ctx();
   h->dev = device_id;
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
@@ -702,6 +869,7 @@ int relate_hip_destroy(relate_hip_t h) {
   h->dRec.release(); h->dPairs.release(); h->dLanePair.release(); h->dParams.release(); h->dOut.release();
   h->dPost.release(); h->dFwd.release(); h->dBp.release(); h->dPath.release(); h->dNsnp.release();
   h->dCm.release(); h->dAstart.release(); h->dBend.release(); h->dCe.release();
+  h->lanebufs[0].release(); h->lanebufs[1].release();
   for (int i = 0; i < 4; i++)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   if (h->stream) (void)hipStreamDestroy(h->stream);

@@ -352,3 +352,38 @@ def test_empty_pair_list_and_repeated_pairs(gpu, prepared):
     v = gpu.like([(0, 1), (0, 1), (1, 0)], pars)
     assert v[0, 0] == v[1, 0]
     assert v[2, 0] == pytest.approx(v[0, 0], rel=1e-12)   # the pair is unordered
+
+
+def test_fit_two_populations_equals_separate_calls(oracle, monkeypatch):
+    """A large block of pairs is fitted as two pair populations that take turns on the GPU (host control of one
+    overlaps the likelihood launch of the other), with whole-turn scheduling and eager restarts.  Pairs are
+    independent, so with the SNP-chunked route switched off (its summation order depends on the lane count) the
+    result must equal, bit for bit, fitting the same pairs in two smaller calls."""
+    import relate_amd
+    from relate_amd import synth
+    monkeypatch.setenv("RELATE_SINGLE_SWEEP_LANES", "1")
+    monkeypatch.setenv("RELATE_FIT_POPULATIONS", "2")
+    N, M = 100, 1500
+    g, pos, chr_, _ = synth.make_dataset(N, M, n_related=10)
+    opt = dict(pc.options("options.all.pair.txt"))
+    opt.update(seed_mode=1, seed=99)
+    H = relate_amd.Relate(0)
+    H.init_globals(g, pos, chr_, opt)
+    pairs = synth.all_pairs(N)[:4200]
+    whole = H.fit(pairs)
+    R = max(1, opt["timesToRun"])
+    rng = np.random.default_rng(3)
+    starts = np.zeros((len(pairs), R, 4))
+    starts[:, :, 0] = rng.uniform(0.01, 0.1, size=(len(pairs), R))
+    starts[:, :, 1] = rng.uniform(0.0, 0.05, size=(len(pairs), R))   # (k1 + 2 k2)^2 >= 4 k2: feasible in calcA mode
+    starts[:, :, 2] = rng.uniform(0.5, 0.9, size=(len(pairs), R))
+    whole_s, conv_w = H.fit(pairs, starts=starts, want_conv=True)
+    monkeypatch.setenv("RELATE_FIT_POPULATIONS", "1")
+    a, conv_a = H.fit(pairs[:2100], starts=starts[:2100], want_conv=True)
+    b, conv_b = H.fit(pairs[2100:], starts=starts[2100:], want_conv=True)
+    keys = sorted(whole_s[0])
+    tab = lambda rows: np.array([[float(r[k]) for k in keys] for r in rows])  # noqa: E731
+    assert np.array_equal(tab(whole_s), tab(a + b), equal_nan=True)  # (a pair at k1 = k2 = 0 has a = nan in calcA mode)
+    assert np.array_equal(conv_w, np.concatenate([conv_a, conv_b]), equal_nan=True)
+    assert np.mean(tab(whole_s)[:, keys.index("negloglik")] < 1e6) > 0.9   # real optimisations, not rejected starts
+    assert sum(r["status"] != 0 for r in whole) == 0 and all(r["timesRun"] >= 1 for r in whole)
