@@ -291,9 +291,8 @@ __device__ inline void stream_records(const EmisRec *__restrict__ col, size_t st
 }
 
 // groups in flight per lane, per kernel (register budget: 32 VGPRs per group)
-#ifndef RELATE_NBUF_CHUNK
-#define RELATE_NBUF_CHUNK 2
-#endif
+// (the chunk-product sweep: a third group measured +-1 % at 220 VGPRs, so it stays at two)
+static constexpr int kNbufChunk = 2;
 static constexpr int kNbuf = 2;  // decode sweeps; measured: 4 costs occupancy (216 vs 152 VGPRs) and gains nothing at 5 TB/s
 
 // forward recursion over rows [sb, se) for NV vectors
@@ -365,7 +364,7 @@ chunk_matrix_kernel(const EmisRec *__restrict__ rec, int M, int RP, const int32_
   int sb = c * chunk_len, se = min(M, sb + chunk_len);
   double x[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
   int ex[3] = {0, 0, 0};
-  sweep<3, DR, RELATE_NBUF_CHUNK>(rec, RP, lane_pair ? lane_pair[l] : l, sb, se, M, C, x, ex);
+  sweep<3, DR, kNbufChunk>(rec, RP, lane_pair ? lane_pair[l] : l, sb, se, M, C, x, ex);
   size_t n = (size_t)nlp * nchunk, at = (size_t)c * nlp + l;
 #pragma unroll
   for (int i = 0; i < 3; i++) {
@@ -434,7 +433,7 @@ like_combine_kernel(ChunkOut O, const double *__restrict__ params, int nlanes, i
 }
 
 // ---- K6 ----------------------------------------------------------------------------------------------------
-// Forward checkpoints (one vector per 8-SNP tile) go to three planes; the boundary vectors of the chunked sweep:
+// Forward checkpoints (one vector per group of kGroup = 4 SNPs) go to three planes; the boundary vectors of the chunked sweep:
 // astart[(c * nlp + p) * 3 ..] = forward vector entering chunk c, bend[...] = backward vector at the last SNP of
 // chunk c.  Any positive scale factor cancels in the posterior, so vectors are normalised with v_rcp_f64.
 __device__ inline void norm_fast(double &x0, double &x1, double &x2) {
