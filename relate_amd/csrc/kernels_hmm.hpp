@@ -532,8 +532,8 @@ decode_fwd_kernel(const EmisRec *__restrict__ rec, int M, int P, int RP, const d
     size_t at = ((size_t)c * nlp + p) * 3;
     x[0][0] = astart[at]; x[0][1] = astart[at + 1]; x[0][2] = astart[at + 2];
   }
-  const size_t stride = (size_t)P;
-  const size_t plane = (size_t)((M + kGroup - 1) / kGroup) * P;
+  const size_t stride = (size_t)RP;  // checkpoint rows share the record pitch (no power-of-two row distance)
+  const size_t plane = (size_t)((M + kGroup - 1) / kGroup) * RP;
   double *kcol = ckpt + p;
   int m = 0;
   stream_records<kNbuf>(
@@ -606,8 +606,8 @@ decode_bwd_kernel(const EmisRec *__restrict__ rec, int M, int P, int RP, const d
     size_t at = ((size_t)c * nlp + pc) * 3;
     b0 = bend[at]; b1 = bend[at + 1]; b2 = bend[at + 2];
   }
-  const size_t stride = (size_t)P;
-  const size_t plane = (size_t)((M + kGroup - 1) / kGroup) * P;
+  const size_t stride = (size_t)RP;  // checkpoint rows share the record pitch (no power-of-two row distance)
+  const size_t plane = (size_t)((M + kGroup - 1) / kGroup) * RP;
   for (int tb = (se - 1) & ~(kTile - 1); tb >= sb; tb -= kTile) {
     int te = min(se, tb + kTile);
 #pragma unroll

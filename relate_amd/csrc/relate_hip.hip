@@ -787,7 +787,7 @@ int decode_block(relate_hip_t h, int P, const double *params, double *post, int8
   HIPCHK(h, hipMemcpyAsync(h->dParams.p, params, sizeof(double) * 3 * P, hipMemcpyHostToDevice, h->stream));
   bool ran = false;
   if (post || nsnp_out || !copy_back) {
-    HIPCHK(h, h->dFwd.ensure((size_t)3 * ((M + 3) / 4) * P));
+    HIPCHK(h, h->dFwd.ensure((size_t)3 * ((M + 3) / 4) * h->recPitch));
     HIPCHK(h, h->dPost.ensure((size_t)3 * M * P));
     int rc = launch_decode(h, P);
     if (rc) return rc;
