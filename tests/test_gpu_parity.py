@@ -387,3 +387,41 @@ def test_fit_two_populations_equals_separate_calls(oracle, monkeypatch):
     assert np.array_equal(conv_w, np.concatenate([conv_a, conv_b]), equal_nan=True)
     assert np.mean(tab(whole_s)[:, keys.index("negloglik")] < 1e6) > 0.9   # real optimisations, not rejected starts
     assert sum(r["status"] != 0 for r in whole) == 0 and all(r["timesRun"] >= 1 for r in whole)
+
+
+def test_full_size_properties_config4():
+    """BASELINE config 4 at its full size (2 000 individuals x 500 000 SNPs), where no oracle sweep is practical:
+    size-independent properties of the HIP path.  (i) the SNP-chunked likelihood of a few lanes equals the single
+    sweep the same points take inside a 45 500-lane launch; (ii) like() does not depend on which other pairs share
+    the launch; (iii) posteriors sum to one, are -1 exactly where a genotype of the pair is missing, and the SNP
+    count is the number of kept SNPs; (iv) decoding with k2 = 0 leaves the IBD2 row at zero (decode(), :1163-1263)."""
+    import relate_amd
+    from relate_amd import synth
+    N, M = 2000, 500000
+    g, pos, chr_, _ = synth.make_dataset(N, M, device="cuda:0")   # same counter-based stream as on the CPU, seconds
+    opt = dict(pc.options("options.all.pair.txt"))
+    H = relate_amd.Relate(0)
+    Ms = H.init_globals(g, pos, chr_, opt)
+    assert Ms > 0.95 * M
+    allp = synth.all_pairs(N)
+    par = np.array([(0.05, 0.1, 0.3), (0.02, 0.25, 0.5), (0.1, 0.0, 0.2), (0.03, 0.05, 0.9), (0.001, 0.0, 1.0)])
+    few = allp[[0, 4000, 9000]]
+    a = H.like(few, np.broadcast_to(par, (3, 5, 3)).copy())
+    assert H.last_chunks()[0] > 1                                   # 15 lanes: cut along the SNP axis
+    many = allp[:9100]
+    b = H.like(many, np.broadcast_to(par, (len(many), 5, 3)).copy())
+    assert H.last_chunks()[0] == 1                                  # 45 500 lanes: one sweep per lane
+    np.testing.assert_allclose(b[[0, 4000, 9000]], a, rtol=1e-12)
+    assert np.isfinite(b).all() and (b > 0).all()
+    sub = many[::7][:1200]
+    c = H.like(sub, np.broadcast_to(par, (len(sub), 5, 3)).copy())
+    np.testing.assert_allclose(c, b[::7][:1200], rtol=1e-12)
+    dpar = np.array([(0.05, 0.1, 0.3), (0.02, 0.0, 0.5), (0.1, 0.2, 0.2)])
+    post, _, ns = H.decode(few, dpar)
+    for n, (i, j) in enumerate(few):
+        miss = (g[i][H.keep == 1] == 0) | (g[j][H.keep == 1] == 0)
+        assert (post[n][:, miss] == -1).all()
+        np.testing.assert_allclose(post[n][:, ~miss].sum(axis=0), 1.0, atol=1e-12)
+        assert (post[n][:, ~miss] >= 0).all()
+        assert ns[n] == int((~miss).sum())
+    assert (post[1][0][post[1][0] != -1] == 0).all()
