@@ -349,7 +349,8 @@ void usage() {
       "\tSYNTAX: flatfiles\n\t./relateHMM_hip -o OPTION -g GENOTYPES -p POSITIONS -c CHROMO -d TESTINDIVIDUALS -v VERBOSE\n"
       "\t-post POSTOUTPUT -k KOUTPUT | -file PREFIX | -out PREFIX\n"
       "\tSYNTAX: plink binary files\n\t./relateHMM_hip -o OPTION -plink PREFIX (or -plink-bed/-plink-bim/-plink-fam)\n"
-      "\textra: -seed N (pin the start points), -gpu D (device ordinal), -est FILE (a, k2, k1, -logL, runs per pair)\n");
+      "\textra: -seed N (pin the start points), -gpu D (device ordinal), -est FILE (a, k2, k1, -logL, runs per pair),\n"
+      "\t       -post-block N (pairs per posterior decode call)\n");
 }
 
 std::string strip_ext(const std::string &p, std::initializer_list<const char *> exts) {
@@ -370,6 +371,7 @@ int main(int argc, char **argv) {
   std::string sg = "stripped.geno", sp = "stripped.pos", sc = "stripped.chr", sk = "keep.index";  // src/conf.h:16-19
   std::string bed, bim, fam, keepfile;
   int plink = 0, verbose = 1, device = 0;
+  long post_block = 0;  // -post-block: pairs per decode call (default: what ~1 GiB of posterior rows holds)
   bool have_seed = false;
   unsigned seed = 0;
   for (int a = 1; a < argc; a += 2) {
@@ -402,6 +404,7 @@ int main(int argc, char **argv) {
     else if (f == "-seed") { seed = (unsigned)std::strtoul(v.c_str(), nullptr, 10); have_seed = true; }
     else if (f == "-gpu") device = std::atoi(v.c_str());
     else if (f == "-est") estF = v;
+    else if (f == "-post-block") post_block = std::atol(v.c_str());
     else { std::printf("\nArgument unknown will exit: %s \n", argv[a]); usage(); return 1; }
   }
   if (verbose) {
@@ -492,38 +495,51 @@ int main(int argc, char **argv) {
   FILE *fest = estF.empty() ? nullptr : std::fopen(estF.c_str(), "w");
   if ((!postF.empty() && !fpost) || (!kF.empty() && !fk) || (!estF.empty() && !fest)) die("cannot open output files");
   const bool k1_only = op.o.fixK == 1 && op.o.fixK_val == 0;  // :3771
-  // block of pairs per library call: bounds the host posterior buffer to ~1 GiB
-  long B = std::max<long>(1, std::min<long>(P, ((long)1 << 30) / ((long)3 * M * (long)sizeof(double))));
-  std::vector<relate_fit> fit((size_t)B);
-  std::vector<double> post((size_t)B * 3 * M);
+  // The fit takes the pairs in large blocks (its launches need tens of thousands of pairs in flight to fill the
+  // GPU); the posteriors of a fitted block are decoded in sub-blocks that bound the host buffer to ~1 GiB.
+  const long FB = std::max<long>(1, std::min<long>(P, 65536));
+  long B = std::max<long>(1, std::min<long>(FB, ((long)1 << 30) / ((long)3 * M * (long)sizeof(double))));
+  if (post_block > 0) B = std::min<long>(FB, post_block);
+  std::vector<relate_fit> fitv((size_t)FB);
+  std::vector<double> post((size_t)B * 3 * M), par((size_t)B * 3);
+  std::vector<int> ns((size_t)B);
   int bad = 0;
-  for (long b0 = 0; b0 < P; b0 += B) {
-    int nb = (int)std::min<long>(B, P - b0);
-    if (relate_hip_run_pairs(h, &pairs[2 * b0], nb, nullptr, fit.data(), post.data(), nullptr))
-      die(relate_hip_last_error(h));
-    for (int p = 0; p < nb; p++) {
-      const double *ibd2 = &post[(size_t)p * 3 * M], *ibd1 = ibd2 + M, *ibd0 = ibd1 + M;
-      (void)ibd2;
-      if (fit[p].status) bad++;
-      if (fpost) {
-        write_post_row(fpost, ibd0, M);
-        if (!k1_only) write_post_row(fpost, ibd1, M);
+  for (long f0 = 0; f0 < P; f0 += FB) {
+    const long nf = std::min<long>(FB, P - f0);
+    if (relate_hip_fit(h, &pairs[2 * f0], (int)nf, nullptr, fitv.data(), nullptr)) die(relate_hip_last_error(h));
+    for (long b0 = f0; b0 < f0 + nf; b0 += B) {
+      int nb = (int)std::min<long>(B, f0 + nf - b0);
+      relate_fit *fit = &fitv[(size_t)(b0 - f0)];
+      for (int p = 0; p < nb; p++) { par[3 * p] = fit[p].a; par[3 * p + 1] = fit[p].k2; par[3 * p + 2] = fit[p].k1; }
+      if (fpost || fest) {  // the posterior rows, and the SNP count of the .est line
+        if (relate_hip_decode(h, &pairs[2 * b0], nb, par.data(), fpost ? post.data() : nullptr, nullptr, ns.data()))
+          die(relate_hip_last_error(h));
+        for (int p = 0; p < nb; p++) fit[p].nsnp = ns[p];
       }
-      if (fk) {
-        // batch drivers: setprecision(POSTPRECISION) (src/relateHMM.cpp:142); lone pair: default precision
-        // (src/runRelate.cpp:70)
-        int prec = batch ? 4 : 6;
-        put_g(fk, fit[p].k1, prec); std::fputc('\n', fk);
-        if (!k1_only) { put_g(fk, fit[p].k2, prec); std::fputc('\n', fk); }
+      for (int p = 0; p < nb; p++) {
+        const double *ibd2 = &post[(size_t)p * 3 * M], *ibd1 = ibd2 + M, *ibd0 = ibd1 + M;
+        (void)ibd2;
+        if (fit[p].status) bad++;
+        if (fpost) {
+          write_post_row(fpost, ibd0, M);
+          if (!k1_only) write_post_row(fpost, ibd1, M);
+        }
+        if (fk) {
+          // batch drivers: setprecision(POSTPRECISION) (src/relateHMM.cpp:142); lone pair: default precision
+          // (src/runRelate.cpp:70)
+          int prec = batch ? 4 : 6;
+          put_g(fk, fit[p].k1, prec); std::fputc('\n', fk);
+          if (!k1_only) { put_g(fk, fit[p].k2, prec); std::fputc('\n', fk); }
+        }
+        if (fest)
+          std::fprintf(fest, "%d\t%d\t%.17g\t%.17g\t%.17g\t%.17g\t%d\t%d\t%d\t%d\n", pairs[2 * (b0 + p)],
+                       pairs[2 * (b0 + p) + 1], fit[p].a, fit[p].k2, fit[p].k1, fit[p].negloglik, fit[p].timesRun,
+                       fit[p].timesConverged, fit[p].nsnp, fit[p].status);
       }
-      if (fest)
-        std::fprintf(fest, "%d\t%d\t%.17g\t%.17g\t%.17g\t%.17g\t%d\t%d\t%d\t%d\n", pairs[2 * (b0 + p)],
-                     pairs[2 * (b0 + p) + 1], fit[p].a, fit[p].k2, fit[p].k1, fit[p].negloglik, fit[p].timesRun,
-                     fit[p].timesConverged, fit[p].nsnp, fit[p].status);
-    }
-    if (verbose) {
-      std::printf("\r\t-> %ld/%ld pairs ", b0 + nb, P);
-      std::fflush(stdout);
+      if (verbose) {
+        std::printf("\r\t-> %ld/%ld pairs ", b0 + nb, P);
+        std::fflush(stdout);
+      }
     }
   }
   if (verbose) std::printf("\n");
