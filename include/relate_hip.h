@@ -74,6 +74,12 @@ typedef struct {
 int relate_hip_create(relate_hip_t *out, int device_id);
 int relate_hip_destroy(relate_hip_t h);
 const char *relate_hip_last_error(relate_hip_t h); /* h may be NULL: error of a failed create */
+/* Result buffers: the reference's callee allocates them (allocDoubleMatrix / allocDoubleArray, src/alloc.cpp:62-309)
+ * and the caller frees them with kill*; here buffers are caller-owned, and a caller that wants posterior rows and
+ * paths to arrive at the speed of the host link allocates them with this pair (page-locked memory: the device
+ * writes it directly).  Any other host memory works too and is staged through the handle's own pinned buffers. */
+int relate_hip_host_alloc(void **out, size_t bytes);
+int relate_hip_host_free(void *p);
 
 /* ---- data set: init_globals -> pre_calc (src/relateHMM.cpp:3371-3392, 3293-3362) --------------- */
 /* geno: N x M_raw row-major (individual-major, as iMatrix data), values 0..3; pos/chr: M_raw, already

@@ -87,6 +87,7 @@ def run(a, handle_factory, dist=None, coll_device=None):
     post_path = "%s.%s.rank%d" % (a.out, "postbin" if binary else "post", rank)
     fh = None if a.no_post else open(post_path, "wb" if binary else "w")
     nrows = 0
+    pin = None   # page-locked posterior buffer of one decode sub-block, reused
     try:
         for b0 in range(0, len(mine), block):
             blk = mine[b0:b0 + block]
@@ -103,7 +104,9 @@ def run(a, handle_factory, dist=None, coll_device=None):
                 if post is None:
                     sub = blk[c0:c0 + post_block]
                     par = [(r["a"], r["k2"], r["k1"]) for r in res[c0:c0 + post_block]]
-                    post, _, _ = H.decode(sub, par)
+                    if pin is None and hasattr(H, "post_buffer"):
+                        pin = H.post_buffer(min(post_block, len(blk)))
+                    post, _, _ = H.decode(sub, par) if pin is None else H.decode(sub, par, out=pin)
                 for n in range(len(post)):
                     if binary:
                         for row in ((2,) if k1_only else (2, 1)):

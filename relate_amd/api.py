@@ -80,12 +80,20 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("librelate_hip.so is not built at %s: run `python -c 'import __graft_entry__ as g; "
                            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: torch ships its own copy of libamdhip64 / libhsa-runtime64.  Loaded after this
+    # library's copy it becomes a second HSA client of the process, and its initialisation then fails ("No HIP GPUs
+    # are available") once this library holds page-locked result buffers.  With torch's copy loaded first the
+    # library's NEEDED entry resolves to that same runtime, which is also what sharing device pointers with torch
+    # (bench.py, synth.py) requires.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.relate_hip_create.argtypes = [C.POINTER(vp), C.c_int]
     L.relate_hip_destroy.argtypes = [vp]
     L.relate_hip_last_error.restype = C.c_char_p
     L.relate_hip_last_error.argtypes = [vp]
+    L.relate_hip_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
+    L.relate_hip_host_free.argtypes = [vp]
     L.relate_hip_load.argtypes = [vp, u8p, C.c_int, C.c_int, dp, ip, C.POINTER(RelateOpts)]
     L.relate_hip_load_bed.argtypes = [vp, u8p, C.c_int, C.c_int, ip, C.c_int, dp, ip, C.POINTER(RelateOpts)]
     L.relate_hip_precalc.argtypes = [vp, ip, ip]
@@ -147,6 +155,22 @@ def shard(P, rank, nranks):
 
 class RelateError(RuntimeError):
     pass
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """numpy array in page-locked host memory (relate_hip_host_alloc): posterior rows and paths written into it by
+    Relate.decode(out=...) arrive by direct DMA instead of through the library's staging buffers.  Freed when the
+    array (and every view of it) is gone."""
+    import weakref
+    L = load_library()
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    ptr = C.c_void_p()
+    if L.relate_hip_host_alloc(C.byref(ptr), n):
+        raise RelateError("relate_hip_host_alloc: %s" % L.relate_hip_last_error(None).decode())
+    buf = (C.c_char * max(n, 1)).from_address(ptr.value)
+    weakref.finalize(buf, L.relate_hip_host_free, C.c_void_p(ptr.value))
+    return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
 
 
 class Relate:
@@ -271,16 +295,28 @@ class Relate:
         res = [{f: getattr(o, f) for f, _ in RelateFit._fields_} for o in out]
         return (res, conv) if want_conv else res
 
-    def decode(self, pairs, params, want_post=True, want_path=False):
+    def decode(self, pairs, params, want_post=True, want_path=False, out=None):
+        """out: optional float64 buffer of at least len(pairs) x 3 x M values (e.g. from pinned_empty) that receives
+        the posteriors; the returned array is a view of it."""
         p, pp = self._pairs(pairs)
         par = np.ascontiguousarray(params, dtype=np.float64).reshape(len(p), 3)
-        post = np.zeros((len(p), 3, self.M)) if want_post else None
+        if out is not None and want_post:
+            flat = out.reshape(-1)
+            if flat.dtype != np.float64 or not flat.flags.c_contiguous or flat.size < len(p) * 3 * self.M:
+                raise ValueError("out must be a contiguous float64 buffer of at least len(pairs) * 3 * M values")
+            post = flat[:len(p) * 3 * self.M].reshape(len(p), 3, self.M)
+        else:
+            post = np.empty((len(p), 3, self.M)) if want_post else None
         path = np.zeros((len(p), self.M), dtype=np.int8) if want_path else None
         ns = np.zeros(len(p), dtype=np.int32)
         self._chk(self.L.relate_hip_decode(self.h, pp, len(p), par.ctypes.data_as(dp),
                                            None if post is None else post.ctypes.data_as(dp),
                                            None if path is None else path.ctypes.data_as(i8p), ns.ctypes.data_as(ip)))
         return post, path, ns
+
+    def post_buffer(self, npairs):
+        """Page-locked buffer for the posteriors of npairs pairs (decode's `out`)."""
+        return pinned_empty((npairs, 3, self.M))
 
     def sgl(self, pairs, starts=None, want_post=True, want_path=False):
         """Body of the reference's pair loop (src/relateHMM.cpp:3764-3785): fit then decode at the estimate."""

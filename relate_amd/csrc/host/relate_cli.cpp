@@ -501,7 +501,10 @@ int main(int argc, char **argv) {
   long B = std::max<long>(1, std::min<long>(FB, ((long)1 << 30) / ((long)3 * M * (long)sizeof(double))));
   if (post_block > 0) B = std::min<long>(FB, post_block);
   std::vector<relate_fit> fitv((size_t)FB);
-  std::vector<double> post((size_t)B * 3 * M), par((size_t)B * 3);
+  std::vector<double> par((size_t)B * 3);
+  double *post = nullptr;  // page-locked: the posterior rows arrive by direct DMA
+  if (fpost && relate_hip_host_alloc((void **)&post, (size_t)B * 3 * M * sizeof(double)))
+    die(relate_hip_last_error(nullptr));
   std::vector<int> ns((size_t)B);
   int bad = 0;
   for (long f0 = 0; f0 < P; f0 += FB) {
@@ -512,13 +515,12 @@ int main(int argc, char **argv) {
       relate_fit *fit = &fitv[(size_t)(b0 - f0)];
       for (int p = 0; p < nb; p++) { par[3 * p] = fit[p].a; par[3 * p + 1] = fit[p].k2; par[3 * p + 2] = fit[p].k1; }
       if (fpost || fest) {  // the posterior rows, and the SNP count of the .est line
-        if (relate_hip_decode(h, &pairs[2 * b0], nb, par.data(), fpost ? post.data() : nullptr, nullptr, ns.data()))
+        if (relate_hip_decode(h, &pairs[2 * b0], nb, par.data(), post, nullptr, ns.data()))
           die(relate_hip_last_error(h));
         for (int p = 0; p < nb; p++) fit[p].nsnp = ns[p];
       }
       for (int p = 0; p < nb; p++) {
-        const double *ibd2 = &post[(size_t)p * 3 * M], *ibd1 = ibd2 + M, *ibd0 = ibd1 + M;
-        (void)ibd2;
+        const double *ibd1 = post ? &post[((size_t)p * 3 + 1) * M] : nullptr, *ibd0 = post ? ibd1 + M : nullptr;
         if (fit[p].status) bad++;
         if (fpost) {
           write_post_row(fpost, ibd0, M);
@@ -547,6 +549,7 @@ int main(int argc, char **argv) {
   if (fpost) std::fclose(fpost);
   if (fk) std::fclose(fk);
   if (fest) std::fclose(fest);
+  relate_hip_host_free(post);
   relate_hip_destroy(h);
   if (verbose) {
     time_t t = time(nullptr);

@@ -293,6 +293,39 @@ def test_scale_properties_chunked_equals_unchunked(gpu, oracle):
     np.testing.assert_allclose(post[0][:, idx], oracle.decode(par[0], *Sk, st["t"], 0), atol=1e-8)
 
 
+def test_result_copy_paths_agree(gpu):
+    """Posteriors and paths reach the caller either by direct DMA (page-locked buffer from relate_hip_host_alloc) or,
+    for ordinary memory, in 32 MiB pieces through the handle's staging buffers: 100 pairs x 3 x 60 000 doubles =
+    144 MB is five pieces with a ragged last one.  Both routes deliver the same bytes; a one-pair call
+    (its path is below the staging threshold) agrees for its pair."""
+    import relate_amd
+    from relate_amd import synth
+    N, M = 40, 60000
+    g, pos, chr_, _ = synth.make_dataset(N, M, n_related=4)
+    opt = dict(pc.options("options.all.pair.txt"))
+    gpu.init_globals(g, pos, chr_, opt)
+    pairs = synth.all_pairs(N)[:100]
+    par = np.tile(np.array([0.05, 0.1, 0.3]), (len(pairs), 1))
+    par[:, 2] = np.linspace(0.05, 0.6, len(pairs))
+    post, path, ns = gpu.decode(pairs, par, want_path=True)
+    assert post.nbytes > 4 * (32 << 20)
+    pin = relate_amd.api.pinned_empty((len(pairs) + 3, 3, gpu.M))
+    pin[:] = 7.0
+    post2, _, ns2 = gpu.decode(pairs, par, out=pin)
+    assert np.shares_memory(post2, pin)
+    assert np.array_equal(post, post2) and np.array_equal(ns, ns2)
+    assert (pin.reshape(-1)[post2.size:] == 7.0).all()          # nothing written past the block
+    one, path1, _ = gpu.decode(pairs[57:58], par[57:58], want_path=True)
+    # (one pair is swept in more SNP chunks than a hundred: same posterior to rounding, same Viterbi path)
+    np.testing.assert_allclose(one[0], post[57], rtol=0, atol=1e-10)
+    assert np.array_equal(path1[0], path[57])
+    ok = post[:, 0, :] != -1
+    np.testing.assert_allclose(post.sum(axis=1)[ok], 1.0, atol=1e-12)
+    assert ((path == -1) == ~ok).all()
+    with pytest.raises(ValueError):
+        gpu.decode(pairs, par, out=pin[:50])
+
+
 def test_errors_are_reported_not_swallowed(gpu, prepared):
     import relate_amd
     b = pc.golden()["blocks"][0]

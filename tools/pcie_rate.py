@@ -14,11 +14,16 @@ H = relate_amd.Relate(0)
 M = H.init_globals(geno, pos, chr_, opt)
 allp = synth.all_pairs(N)
 par = bench.eval_points(P, E)
-for it in range(3):
-    blk = allp[it * P:(it + 1) * P]
+pin = H.post_buffer(P)
+for it in range(6):
+    blk = allp[(it % 3) * P:(it % 3 + 1) * P]
+    pinned = it >= 3          # first three steps: ordinary numpy memory; last three: page-locked buffer
     t0 = time.perf_counter()
     H.like(blk, par)
-    post, _, _ = H.decode(blk, np.ascontiguousarray(par[:, 0, :]))
+    t1 = time.perf_counter()
+    post, _, _ = H.decode(blk, np.ascontiguousarray(par[:, 0, :]), out=pin if pinned else None)
     dt = time.perf_counter() - t0
-    print("P=%d M=%d: %.1f ms per step with host buffers = %.3g HMM steps/s (posterior copy-back %.2f GB)" % (
-        P, M, dt * 1e3, P * M * (E + 2) / dt, post.nbytes / 1e9), flush=True)
+    print("P=%d M=%d %s: %.1f ms per step with host buffers (decode + copy-back %.1f ms) = %.3g HMM steps/s "
+          "(posterior copy-back %.2f GB)" % (P, M, "pinned" if pinned else "pageable", dt * 1e3,
+                                             (time.perf_counter() - t1) * 1e3, P * M * (E + 2) / dt,
+                                             post.nbytes / 1e9), flush=True)
