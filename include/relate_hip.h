@@ -144,6 +144,15 @@ int relate_findmax_bfgs(int numpars, double *invec, double (*fun)(double *x, voi
  * src/relateHMM.cpp:278-293, 1546-1560).  out[i] = i-th rand() after srand(seed). */
 void relate_rand_stream(unsigned int seed, int n, int *out);
 
+/* ---- output text ---------------------------------------------------------------------------------- */
+/* write_dMatrix_to_file (src/relateHMM.cpp:117-136, POSTPRECISION src/conf.h:8) for a block of posteriors as
+ * relate_hip_decode returns them (P x 3 x M): per pair the IBD0 row, then the IBD1 row unless k1_only (fixK2 = 1 with
+ * value 0, :3771); each value as "%.4g" + tab, "-1" for dropped SNPs, newline after the row -- the bytes the reference's
+ * ostream writes.  Host threads only, no GPU.  out: (P * rows) x relate_post_text_stride(M) bytes; row r starts at
+ * out + r * stride and is row_len[r] bytes long (no terminator). */
+size_t relate_post_text_stride(int M);
+int relate_format_post_rows(const double *post, int P, int M, int k1_only, char *out, size_t *row_len);
+
 /* ---- multi-GPU: contiguous pair-block partition (no data-path collective) ------------------------ */
 /* Rank r of nranks owns pairs [*begin, *end) of a list of P pairs. */
 void relate_hip_shard(int64_t P, int rank, int nranks, int64_t *begin, int64_t *end);

@@ -85,7 +85,7 @@ def run(a, handle_factory, dist=None, coll_device=None):
     fits = []
     binary = getattr(a, "post_format", "text") == "bin"
     post_path = "%s.%s.rank%d" % (a.out, "postbin" if binary else "post", rank)
-    fh = None if a.no_post else open(post_path, "wb" if binary else "w")
+    fh = None if a.no_post else open(post_path, "wb")
     nrows = 0
     pin = None   # page-locked posterior buffer of one decode sub-block, reused
     try:
@@ -107,13 +107,13 @@ def run(a, handle_factory, dist=None, coll_device=None):
                     if pin is None and hasattr(H, "post_buffer"):
                         pin = H.post_buffer(min(post_block, len(blk)))
                     post, _, _ = H.decode(sub, par) if pin is None else H.decode(sub, par, out=pin)
-                for n in range(len(post)):
-                    if binary:
+                if binary:
+                    for n in range(len(post)):
                         for row in ((2,) if k1_only else (2, 1)):
                             fh.write(np.asarray(post[n][row], dtype="<f4").tobytes())
-                    else:
-                        rio.write_post_rows(fh, post[n], k1_only)
-                    nrows += 1 if k1_only else 2
+                else:
+                    rio.write_post_block(fh, post, k1_only)
+                nrows += len(post) * (1 if k1_only else 2)
     finally:
         if fh is not None:
             fh.close()

@@ -94,6 +94,9 @@ def load_library():
     L.relate_hip_last_error.argtypes = [vp]
     L.relate_hip_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
     L.relate_hip_host_free.argtypes = [vp]
+    L.relate_post_text_stride.restype = C.c_size_t
+    L.relate_post_text_stride.argtypes = [C.c_int]
+    L.relate_format_post_rows.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_size_t)]
     L.relate_hip_load.argtypes = [vp, u8p, C.c_int, C.c_int, dp, ip, C.POINTER(RelateOpts)]
     L.relate_hip_load_bed.argtypes = [vp, u8p, C.c_int, C.c_int, ip, C.c_int, dp, ip, C.POINTER(RelateOpts)]
     L.relate_hip_precalc.argtypes = [vp, ip, ip]

@@ -303,15 +303,24 @@ std::vector<int32_t> keep_list_pairs(const std::string &path) {
 // ostream << setprecision(p) << double  ==  printf("%.{p}g")
 void put_g(FILE *f, double v, int prec) { std::fprintf(f, "%.*g", prec, v); }
 
-// write_dMatrix_to_file (src/relateHMM.cpp:117-136): one posterior row, tab after every value, -1 for SNPs
-// dropped for the pair (the library marks them with -1 already), 4 significant digits (POSTPRECISION)
-void write_post_row(FILE *f, const double *row, int M) {
-  for (int s = 0; s < M; s++) {
-    if (row[s] == -1.0) std::fputs("-1", f);
-    else put_g(f, row[s], 4);
-    std::fputc('\t', f);
+// write_dMatrix_to_file (src/relateHMM.cpp:117-136) for a decoded block: per pair the IBD0 row and, unless k2 is
+// fixed at 0, the IBD1 row (:3771-3782); tab after every value, -1 for SNPs dropped for the pair, 4 significant digits
+// (POSTPRECISION).  The library formats the rows on the host threads (printf's bytes, relate_format_post_rows);
+// groups of pairs bound the text buffer to ~256 MiB.
+void write_post_block(FILE *f, const double *post, int nb, int M, bool k1_only, std::vector<char> &text,
+                      std::vector<size_t> &len) {
+  const size_t stride = relate_post_text_stride(M);
+  const int rpp = k1_only ? 1 : 2;
+  const int group = (int)std::max<size_t>(1, std::min<size_t>((size_t)nb, ((size_t)256 << 20) / (stride * rpp)));
+  text.resize((size_t)group * rpp * stride);
+  len.resize((size_t)group * rpp);
+  for (int g0 = 0; g0 < nb; g0 += group) {
+    const int ng = std::min(group, nb - g0);
+    if (relate_format_post_rows(post + (size_t)g0 * 3 * M, ng, M, k1_only ? 1 : 0, text.data(), len.data()))
+      die(relate_hip_last_error(nullptr));
+    for (int r = 0; r < ng * rpp; r++)
+      if (std::fwrite(text.data() + (size_t)r * stride, 1, len[r], f) != len[r]) die("cannot write the .post file");
   }
-  std::fputc('\n', f);
 }
 
 void dump_stripped(relate_hip_t h, const DataSet &d, const std::vector<int> &keep, int M, const std::string &fg,
@@ -506,6 +515,8 @@ int main(int argc, char **argv) {
   if (fpost && relate_hip_host_alloc((void **)&post, (size_t)B * 3 * M * sizeof(double)))
     die(relate_hip_last_error(nullptr));
   std::vector<int> ns((size_t)B);
+  std::vector<char> text;           // formatted rows of a group of pairs (write_post_block)
+  std::vector<size_t> text_len;
   int bad = 0;
   for (long f0 = 0; f0 < P; f0 += FB) {
     const long nf = std::min<long>(FB, P - f0);
@@ -519,13 +530,9 @@ int main(int argc, char **argv) {
           die(relate_hip_last_error(h));
         for (int p = 0; p < nb; p++) fit[p].nsnp = ns[p];
       }
+      if (fpost) write_post_block(fpost, post, nb, M, k1_only, text, text_len);
       for (int p = 0; p < nb; p++) {
-        const double *ibd1 = post ? &post[((size_t)p * 3 + 1) * M] : nullptr, *ibd0 = post ? ibd1 + M : nullptr;
         if (fit[p].status) bad++;
-        if (fpost) {
-          write_post_row(fpost, ibd0, M);
-          if (!k1_only) write_post_row(fpost, ibd1, M);
-        }
         if (fk) {
           // batch drivers: setprecision(POSTPRECISION) (src/relateHMM.cpp:142); lone pair: default precision
           // (src/runRelate.cpp:70)

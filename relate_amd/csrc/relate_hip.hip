@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -24,6 +25,7 @@
 #include "kernels_hmm.hpp"
 #include "kernels_linkage.hpp"
 #include "kernels_precalc.hpp"
+#include "post_text.hpp"
 
 using namespace relate;
 
@@ -957,6 +959,31 @@ int relate_hip_host_free(void *p) {
   }
   hipError_t e = hipHostFree(p);
   if (e != hipSuccess) return fail(nullptr, RELATE_E_HIP, std::string("hipHostFree: ") + hipGetErrorString(e));
+  return RELATE_OK;
+}
+
+size_t relate_post_text_stride(int M) { return (size_t)(M > 0 ? M : 0) * relate_text::kMaxValueChars + 2; }
+
+int relate_format_post_rows(const double *post, int P, int M, int k1_only, char *out, size_t *row_len) {
+  if (!post || !out || !row_len || P < 0 || M < 1) return fail(nullptr, RELATE_E_ARG, "bad arguments");
+  const int rpp = k1_only ? 1 : 2;
+  const long nrows = (long)P * rpp;
+  const size_t stride = relate_post_text_stride(M);
+  (void)relate_text::pow10_table();  // built before the threads start
+  std::atomic<long> next{0};
+  auto work = [&] {
+    for (long r = next.fetch_add(1); r < nrows; r = next.fetch_add(1)) {
+      const long p = r / rpp;
+      const int which = (r % rpp) ? 1 : 2;  // IBD0 row (2) first, then the IBD1 row (1), :3771-3782
+      row_len[r] = relate_text::format_row(post + ((size_t)p * 3 + which) * M, M, out + (size_t)r * stride);
+    }
+  };
+  int nt = (int)std::min<long>(host_threads(), nrows);
+  if ((long)nrows * M < 65536) nt = 1;
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; t++) th.emplace_back(work);
+  work();
+  for (auto &x : th) x.join();
   return RELATE_OK;
 }
 

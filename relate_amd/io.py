@@ -178,3 +178,29 @@ def write_post_rows(fh, post, k1_only):
     for row in ((2,) if k1_only else (2, 1)):
         fh.write("".join(("-1\t" if v == -1.0 else fmt_g(v) + "\t") for v in post[row]))
         fh.write("\n")
+
+
+def write_post_block(fh, post, k1_only):
+    """write_dMatrix_to_file for a decoded block (P x 3 x M) into a file opened in binary mode: the same bytes as
+    write_post_rows pair by pair, formatted by the library's host threads (relate_format_post_rows; 10^8 values a second
+    instead of 10^6)."""
+    import ctypes as C
+    from . import api
+    L = api.load_library()
+    post = np.ascontiguousarray(post, dtype=np.float64)
+    P, three, M = post.shape
+    assert three == 3
+    stride = L.relate_post_text_stride(M)
+    rpp = 1 if k1_only else 2
+    group = max(1, min(P, (256 << 20) // (stride * rpp)))
+    out = C.create_string_buffer(group * rpp * stride)
+    lens = (C.c_size_t * (group * rpp))()
+    view = memoryview(out)
+    for g0 in range(0, P, group):
+        ng = min(group, P - g0)
+        rc = L.relate_format_post_rows(post[g0:g0 + ng].ctypes.data_as(api.dp), ng, M, int(k1_only), out, lens)
+        if rc:
+            raise api.RelateError(L.relate_hip_last_error(None).decode())
+        for r in range(ng * rpp):
+            fh.write(view[r * stride:r * stride + lens[r]])
+
