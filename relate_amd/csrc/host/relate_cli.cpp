@@ -94,25 +94,40 @@ struct DataSet {
   std::vector<int> chr;
 };
 
+// readmatrix (:317-417) for the genotype file, streamed line by line into the byte matrix (a token vector of a
+// 2 000 x 500 000 file would not fit in memory)
 void read_geno_text(const std::string &path, DataSet *d) {
-  std::vector<std::string> tok;
-  std::vector<size_t> rows;
-  read_tokens(path, &tok, &rows);
-  if (rows.empty()) die("genotype file is empty: " + path);
-  for (size_t r = 1; r < rows.size(); r++)
-    if (rows[r] != rows[0])
-      die("row length mismatch at line:" + std::to_string(r + 1) + " numitems is:" + std::to_string(rows[0]) +
-          " shouldn't be:" + std::to_string(rows[r]) + "\t will exit");
-  d->N = (int)rows.size();
-  d->M = (int)rows[0];
-  d->geno.resize(tok.size());
-  for (size_t i = 0; i < tok.size(); i++) {
-    int v = token_to_int(tok[i]);
-    if (v < 0 || v > 3)
-      die("Error in genotype data: (" + std::to_string(i / d->M) + "," + std::to_string(i % d->M) + ")=" +
-          std::to_string(v) + ", value should be between 0 and 3.");
-    d->geno[i] = (uint8_t)v;
+  std::ifstream in(path);
+  if (!in) die("Problems opening file: " + path + "\t right directory?");
+  std::string line, tok;
+  size_t first = 0, nrows = 0;
+  while (std::getline(in, line)) {
+    size_t n = 0, i = 0;
+    while (i < line.size()) {
+      size_t b = line.find_first_not_of(kDelims, i);
+      if (b == std::string::npos) break;
+      size_t e = line.find_first_of(kDelims, b);
+      if (e == std::string::npos) e = line.size();
+      int v;
+      if (e - b == 1 && line[b] >= '0' && line[b] <= '9') v = line[b] - '0';
+      else { tok.assign(line, b, e - b); v = token_to_int(tok); }
+      if (v < 0 || v > 3)
+        die("Error in genotype data: (" + std::to_string(nrows) + "," + std::to_string(n) + ")=" + std::to_string(v) +
+            ", value should be between 0 and 3.");
+      d->geno.push_back((uint8_t)v);
+      n++;
+      i = e;
+    }
+    if (!n) continue;  // blank line
+    if (!nrows) { first = n; d->geno.reserve(first * 128); }
+    else if (n != first)
+      die("row length mismatch at line:" + std::to_string(nrows + 1) + " numitems is:" + std::to_string(first) +
+          " shouldn't be:" + std::to_string(n) + "\t will exit");
+    nrows++;
   }
+  if (!nrows) die("genotype file is empty: " + path);
+  d->N = (int)nrows;
+  d->M = (int)first;
 }
 
 // 27-line option file: first tab-separated token of each line through atof into a float
@@ -330,9 +345,12 @@ void dump_stripped(relate_hip_t h, const DataSet &d, const std::vector<int> &kee
   if (relate_hip_get_stripped(h, g.data(), pos.data(), nullptr)) die(relate_hip_last_error(h));
   FILE *f = std::fopen(fg.c_str(), "w");  // iMatrix::print, src/types.h:34-56
   if (!f) die("cannot write " + fg);
+  std::vector<char> line((size_t)2 * M + 1);  // "%d " of a value 0..3 is two characters
   for (int i = 0; i < d.N; i++) {
-    for (int s = 0; s < M; s++) std::fprintf(f, "%d ", (int)g[(size_t)i * M + s]);
-    std::fputc('\n', f);
+    const uint8_t *row = &g[(size_t)i * M];
+    for (int s = 0; s < M; s++) { line[2 * (size_t)s] = (char)('0' + row[s]); line[2 * (size_t)s + 1] = ' '; }
+    line[(size_t)2 * M] = '\n';
+    if (std::fwrite(line.data(), 1, line.size(), f) != line.size()) die("cannot write " + fg);
   }
   std::fclose(f);
   f = std::fopen(fp.c_str(), "w");  // dArray::print, :160-179
