@@ -132,6 +132,21 @@ def cpu_baseline(H, opt, E, want_seconds=12.0):
                           dt)}
 
 
+def fit_leg(H, allp, npairs, M):
+    """Outside the timed region and not part of `value`: the whole estimation (relate_hip_fit: up to 8 restarts of the
+    2-parameter L-BFGS-B search per pair, every objective value a likelihood sweep on the GPU) on the first pairs of the
+    same data set, wall-clock around the C-ABI call -- what a user of the all-pairs scan waits for."""
+    blk = allp[:npairs]
+    t0 = time.perf_counter()
+    res = H.fit(blk)
+    dt = time.perf_counter() - t0
+    tm = H.timings()
+    return {"pairs": int(npairs), "seconds": dt, "pairs_per_s": npairs / dt, "pair_snp_per_s": npairs * M / dt,
+            "like_kernel_seconds": tm["like_ms"] / 1e3, "restarts_per_pair": sum(r["timesRun"] for r in res) / npairs,
+            "pairs_with_nan": int(sum(r["status"] != 0 for r in res)),
+            "note": "relate_hip_fit, options.all.pair.txt semantics (calcA, timesToRun 8); not part of value"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,7 +156,9 @@ def main():
     ap.add_argument("--snps", type=int, default=500000)
     ap.add_argument("--pairs", type=int, default=2048, help="pairs per block per GPU")
     ap.add_argument("--points", type=int, default=5, help="evaluation points per pair per like launch")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="bench line only: no cpu_baseline, no fit leg")
+    ap.add_argument("--no-fit", action="store_true")
+    ap.add_argument("--fit-pairs", type=int, default=8192)
     args = ap.parse_args()
 
     import torch
@@ -269,6 +286,8 @@ def main():
             "kernels_hbm_frac": {k: v / HBM_PEAK_GBS for k, v in gbs.items()},
             "setup_s": {"synthetic_data": t_gen, "load_precalc": t_pre},
         }
+        if world == 1 and not args.no_cpu and not args.no_fit:
+            line["fit"] = fit_leg(H, mine, min(args.fit_pairs, len(mine)), M)
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(H, opt, E)
         print(json.dumps(line))
