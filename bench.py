@@ -256,7 +256,7 @@ def main():
         traffic = pmc_traffic(P, M, E)
         tkey = {"stage": ["relate::stage_pairs_win_kernel"], "like": ["relate::chunk_matrix_kernel<false>"],
                 "decode_fwd": ["relate::chunk_matrix_kernel<false>", "relate::decode_fwd_kernel<false>"],
-                "decode_bwd": ["relate::decode_bwd_kernel<false>"]}[dom]
+                "decode_bwd": ["relate::decode_bwd_kernel<false, double>"]}[dom]
         tr = sum(traffic[k] for k in tkey) if traffic and all(k in traffic for k in tkey) else None
         like_steps_s = P * M * E / (per["like"] * 1e-3)
         valu = VALU_PER_STEP[3 if lc > 1 else 1]

@@ -130,6 +130,14 @@ int relate_hip_fit(relate_hip_t h, const int32_t *pairs, int P, const double *st
 int relate_hip_decode(relate_hip_t h, const int32_t *pairs, int P, const double *params, double *post,
                       int8_t *path, int *nsnp_out);
 
+/* The same decode with the rows the .post writer keeps (write_dMatrix_to_file of row 2 = IBD0, then row 1 = IBD1
+ * unless fixK2 = 1 with value 0, src/relateHMM.cpp:3771-3782) as floats: post is P x rows x M, row 0 = IBD0, row 1 =
+ * IBD1, row 2 = IBD2 (rows = 1..3), each value the double posterior rounded once to float (7 digits against the 4 the
+ * reference prints), -1 where the SNP is dropped.  A third of the bytes over the host link; the layout of the binary
+ * shards of relate_amd.allpairs. */
+int relate_hip_decode_f32(relate_hip_t h, const int32_t *pairs, int P, const double *params, int rows, float *post,
+                          int *nsnp_out);
+
 /* sgl for P pairs: fit (or doPar) then decode at the estimate -- the body of the reference's pair loop. */
 int relate_hip_run_pairs(relate_hip_t h, const int32_t *pairs, int P, const double *starts, relate_fit *out,
                          double *post, int8_t *path);

@@ -89,31 +89,34 @@ def run(a, handle_factory, dist=None, coll_device=None):
     nrows = 0
     pin = None   # page-locked posterior buffer of one decode sub-block, reused
     try:
+        rows = 1 if k1_only else 2
         for b0 in range(0, len(mine), block):
             blk = mine[b0:b0 + block]
-            if fh is None or len(blk) <= post_block:
-                res, post, _ = H.sgl(blk, want_post=fh is not None)
-                chunks = [(0, post)]
-            else:
-                res, _, _ = H.sgl(blk, want_post=False)   # fit (+ SNP counts); posteriors follow in sub-blocks
-                chunks = ((c0, None) for c0 in range(0, len(blk), post_block))
-            fits.extend(res)
             if fh is None:
+                fits.extend(H.sgl(blk, want_post=False)[0])
                 continue
-            for c0, post in chunks:
-                if post is None:
-                    sub = blk[c0:c0 + post_block]
-                    par = [(r["a"], r["k2"], r["k1"]) for r in res[c0:c0 + post_block]]
+            if len(blk) <= post_block and not binary:
+                res, post, _ = H.sgl(blk)
+                fits.extend(res)
+                rio.write_post_block(fh, post, k1_only)
+                nrows += len(blk) * rows
+                continue
+            res, _, _ = H.sgl(blk, want_post=False)   # fit (+ SNP counts); posteriors follow in sub-blocks
+            fits.extend(res)
+            for c0 in range(0, len(blk), post_block):
+                sub = blk[c0:c0 + post_block]
+                par = [(r["a"], r["k2"], r["k1"]) for r in res[c0:c0 + post_block]]
+                if binary:   # float32 rows in writer order straight from the GPU: the shard's own layout
+                    if pin is None and hasattr(H, "post_buffer"):
+                        pin = H.post_buffer(min(post_block, len(blk)), rows, np.float32)
+                    post, _ = H.decode_f32(sub, par, rows) if pin is None else H.decode_f32(sub, par, rows, out=pin)
+                    fh.write(memoryview(np.ascontiguousarray(post, dtype="<f4")).cast("B"))
+                else:
                     if pin is None and hasattr(H, "post_buffer"):
                         pin = H.post_buffer(min(post_block, len(blk)))
                     post, _, _ = H.decode(sub, par) if pin is None else H.decode(sub, par, out=pin)
-                if binary:
-                    for n in range(len(post)):
-                        for row in ((2,) if k1_only else (2, 1)):
-                            fh.write(np.asarray(post[n][row], dtype="<f4").tobytes())
-                else:
                     rio.write_post_block(fh, post, k1_only)
-                nrows += len(post) * (1 if k1_only else 2)
+                nrows += len(sub) * rows
     finally:
         if fh is not None:
             fh.close()

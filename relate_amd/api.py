@@ -106,6 +106,7 @@ def load_library():
     L.relate_hip_like.argtypes = [vp, i32p, C.c_int, dp, C.c_int, dp]
     L.relate_hip_fit.argtypes = [vp, i32p, C.c_int, dp, C.POINTER(RelateFit), dp]
     L.relate_hip_decode.argtypes = [vp, i32p, C.c_int, dp, dp, i8p, ip]
+    L.relate_hip_decode_f32.argtypes = [vp, i32p, C.c_int, dp, C.c_int, C.POINTER(C.c_float), ip]
     L.relate_hip_run_pairs.argtypes = [vp, i32p, C.c_int, dp, C.POINTER(RelateFit), dp, i8p]
     L.relate_rand_stream.argtypes = [C.c_uint, C.c_int, ip]
     L.relate_rand_stream.restype = None
@@ -317,9 +318,27 @@ class Relate:
                                            None if path is None else path.ctypes.data_as(i8p), ns.ctypes.data_as(ip)))
         return post, path, ns
 
-    def post_buffer(self, npairs):
+    def decode_f32(self, pairs, params, rows=2, out=None):
+        """Posterior rows in the .post writer's order (IBD0, IBD1[, IBD2]) as float32: (len(pairs), rows, M).
+        out: optional float32 buffer (e.g. pinned_empty(..., np.float32)) that receives them."""
+        p, pp = self._pairs(pairs)
+        par = np.ascontiguousarray(params, dtype=np.float64).reshape(len(p), 3)
+        n = len(p) * rows * self.M
+        if out is not None:
+            flat = out.reshape(-1)
+            if flat.dtype != np.float32 or not flat.flags.c_contiguous or flat.size < n:
+                raise ValueError("out must be a contiguous float32 buffer of at least len(pairs) * rows * M values")
+            post = flat[:n].reshape(len(p), rows, self.M)
+        else:
+            post = np.empty((len(p), rows, self.M), dtype=np.float32)
+        ns = np.zeros(len(p), dtype=np.int32)
+        self._chk(self.L.relate_hip_decode_f32(self.h, pp, len(p), par.ctypes.data_as(dp), rows,
+                                               post.ctypes.data_as(C.POINTER(C.c_float)), ns.ctypes.data_as(ip)))
+        return post, ns
+
+    def post_buffer(self, npairs, rows=3, dtype=np.float64):
         """Page-locked buffer for the posteriors of npairs pairs (decode's `out`)."""
-        return pinned_empty((npairs, 3, self.M))
+        return pinned_empty((npairs, rows, self.M), dtype)
 
     def sgl(self, pairs, starts=None, want_post=True, want_path=False):
         """Body of the reference's pair loop (src/relateHMM.cpp:3764-3785): fit then decode at the estimate."""

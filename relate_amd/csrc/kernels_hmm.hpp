@@ -586,11 +586,14 @@ __device__ inline void dec_bwd_half(const LaneC &C, const EmisRec (&R)[kGroup], 
   }
 }
 
-template <bool DR>
+// OutT = double: post[p][3][M], rows IBD2, IBD1, IBD0 (the reference's dMatrix).  OutT = float: post[p][rows][M] in
+// the order the .post writer takes them (IBD0, IBD1, IBD2; :3771-3782), the first `rows` of them, each value the
+// double result rounded once to float.
+template <bool DR, typename OutT>
 __global__ void __launch_bounds__(kBwdThreads)
 decode_bwd_kernel(const EmisRec *__restrict__ rec, int M, int P, int RP, const double *__restrict__ params, int nlp,
                   int chunk_len, const double *__restrict__ bend, const double *__restrict__ ckpt,
-                  double *__restrict__ post) {
+                  OutT *__restrict__ post, int rows) {
   __shared__ double tile[3][kBwdThreads][kTilePad];
   int bpc = (P + kBwdThreads - 1) / kBwdThreads;
   int c = blockIdx.x / bpc;
@@ -631,7 +634,12 @@ decode_bwd_kernel(const EmisRec *__restrict__ rec, int M, int P, int RP, const d
       int idx = j * kBwdThreads + threadIdx.x;
       int e = idx % kTile, pr = (idx / kTile) % kBwdThreads, r = idx / (kTile * kBwdThreads);
       int s = tb + e, pp = pbase + pr;
-      if (s < te && pp < P) post[((size_t)pp * 3 + r) * M + s] = tile[r][pr][e];
+      if constexpr (sizeof(OutT) == sizeof(double)) {
+        if (s < te && pp < P) post[((size_t)pp * 3 + r) * M + s] = tile[r][pr][e];
+      } else {
+        int rr = 2 - r;
+        if (s < te && pp < P && rr < rows) post[((size_t)pp * rows + rr) * M + s] = (OutT)tile[r][pr][e];
+      }
     }
     __syncthreads();
   }

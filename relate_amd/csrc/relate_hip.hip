@@ -783,7 +783,8 @@ int copy_to_host(relate_hip_t h, void *dst, const void *src, size_t bytes) {
 }
 
 // K6 launches for the staged block with params already in dParams; posteriors left in dPost
-int launch_decode(relate_hip_t h, int P) {
+// (f32_rows: 0 = doubles, P x 3 x M; 1..3 = floats, P x f32_rows x M in writer order, in the same buffer)
+int launch_decode(relate_hip_t h, int P, int f32_rows = 0) {
   const int M = h->M;
   int nchunk, clen;
   pick_chunks(M, P, 256, h->slots_decode, 1, &nchunk, &clen);
@@ -823,32 +824,42 @@ int launch_decode(relate_hip_t h, int P) {
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
   dim3 bgrid((unsigned)((size_t)((P + kBwdThreads - 1) / kBwdThreads) * nchunk));
-  if (dr)
-    hipLaunchKernelGGL(decode_bwd_kernel<true>, bgrid, dim3(kBwdThreads), 0, h->stream, h->dRec.p, M, P, h->recPitch, h->dParams.p,
-                       nlp, clen, bend, h->dFwd.p, h->dPost.p);
-  else
-    hipLaunchKernelGGL(decode_bwd_kernel<false>, bgrid, dim3(kBwdThreads), 0, h->stream, h->dRec.p, M, P, h->recPitch,
-                       h->dParams.p, nlp, clen, bend, h->dFwd.p, h->dPost.p);
+#define LAUNCH_BWD(DRV, T, OUT, ROWS)                                                                                  \
+  hipLaunchKernelGGL((decode_bwd_kernel<DRV, T>), bgrid, dim3(kBwdThreads), 0, h->stream, h->dRec.p, M, P, h->recPitch, \
+                     h->dParams.p, nlp, clen, bend, h->dFwd.p, OUT, ROWS)
+  if (f32_rows) {
+    float *pf = reinterpret_cast<float *>(h->dPost.p);
+    if (dr) LAUNCH_BWD(true, float, pf, f32_rows);
+    else LAUNCH_BWD(false, float, pf, f32_rows);
+  } else {
+    if (dr) LAUNCH_BWD(true, double, h->dPost.p, 3);
+    else LAUNCH_BWD(false, double, h->dPost.p, 3);
+  }
+#undef LAUNCH_BWD
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
   return 0;
 }
 
 int decode_block(relate_hip_t h, int P, const double *params, double *post, int8_t *path, int *nsnp_out,
-                 bool copy_back) {
+                 bool copy_back, float *post32 = nullptr, int f32_rows = 0) {
   const int M = h->M;
   HIPCHK(h, h->dParams.ensure((size_t)3 * P));
   HIPCHK(h, h->dNsnp.ensure(P));
   HIPCHK(h, hipMemcpyAsync(h->dParams.p, params, sizeof(double) * 3 * P, hipMemcpyHostToDevice, h->stream));
   bool ran = false;
-  if (post || nsnp_out || !copy_back) {
+  if (post || post32 || nsnp_out || !copy_back) {
     HIPCHK(h, h->dFwd.ensure((size_t)3 * ((M + 3) / 4) * h->recPitch));
-    HIPCHK(h, h->dPost.ensure((size_t)3 * M * P));
-    int rc = launch_decode(h, P);
+    HIPCHK(h, h->dPost.ensure(post32 ? ((size_t)f32_rows * M * P + 1) / 2 : (size_t)3 * M * P));
+    int rc = launch_decode(h, P, post32 ? f32_rows : 0);
     if (rc) return rc;
     if (nsnp_out) HIPCHK(h, hipMemcpyAsync(nsnp_out, h->dNsnp.p, sizeof(int) * P, hipMemcpyDeviceToHost, h->stream));
     if (copy_back && post) {
       rc = copy_to_host(h, post, h->dPost.p, sizeof(double) * 3 * M * P);
+      if (rc) return rc;
+    }
+    if (copy_back && post32) {
+      rc = copy_to_host(h, post32, h->dPost.p, sizeof(float) * (size_t)f32_rows * M * P);
       if (rc) return rc;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -908,7 +919,7 @@ int relate_hip_create(relate_hip_t *out, int device_id) {
       ncu = prop.multiProcessorCount;
     long sc = wave_slots(chunk_matrix_kernel<false>, 256, ncu);
     long sf = wave_slots(decode_fwd_kernel<false>, 256, ncu);
-    long sb = wave_slots(decode_bwd_kernel<false>, kBwdThreads, ncu);
+    long sb = wave_slots(decode_bwd_kernel<false, double>, kBwdThreads, ncu);
     h->slots_like = sc;
     // decode launches (P / 64) waves per chunk in each of its three sweeps
     h->slots_decode = lcm(lcm(sc, sf), sb);
@@ -1360,6 +1371,25 @@ int relate_hip_decode(relate_hip_t h, const int32_t *pairs, int P, const double 
     if (rc) return rc;
     rc = decode_block(h, pb, params + 3 * b0, post ? post + (size_t)b0 * 3 * h->M : nullptr,
                       path ? path + (size_t)b0 * h->M : nullptr, nsnp_out ? nsnp_out + b0 : nullptr, true);
+    if (rc) return rc;
+  }
+  return RELATE_OK;
+}
+
+int relate_hip_decode_f32(relate_hip_t h, const int32_t *pairs, int P, const double *params, int rows, float *post,
+                          int *nsnp_out) {
+  int rc = require_ready(h);
+  if (rc) return rc;
+  if (!pairs || !params || !post || P < 0 || rows < 1 || rows > 3) return fail(h, RELATE_E_ARG, "bad arguments");
+  h->timings[2] = h->timings[3] = 0;
+  size_t lim = pair_block_limit(h, sizeof(EmisRec) + rows * sizeof(float) + 8,
+                                h->dRec.cap * sizeof(EmisRec) + (h->dPost.cap + h->dFwd.cap) * sizeof(double));
+  for (long b0 = 0; b0 < P; b0 += (long)lim) {
+    int pb = (int)std::min<long>((long)lim, P - b0);
+    rc = stage_block(h, pairs + 2 * b0, pb);
+    if (rc) return rc;
+    rc = decode_block(h, pb, params + 3 * b0, nullptr, nullptr, nsnp_out ? nsnp_out + b0 : nullptr, true,
+                      post + (size_t)b0 * rows * h->M, rows);
     if (rc) return rc;
   }
   return RELATE_OK;

@@ -34,6 +34,10 @@ class FakeHandle:
             post[n][:, 3] = -1
         return post, None, np.full(len(pairs), self.M, dtype=np.int32)
 
+    def decode_f32(self, pairs, params, rows=2, out=None):
+        post, _, ns = self.decode(pairs, params)
+        return np.ascontiguousarray(post[:, [2, 1, 0][:rows], :], dtype=np.float32), ns
+
 
 def _free_port():
     s = socket.socket()

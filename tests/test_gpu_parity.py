@@ -326,12 +326,40 @@ def test_result_copy_paths_agree(gpu):
         gpu.decode(pairs, par, out=pin[:50])
 
 
+@pytest.mark.parametrize("rows", [1, 2, 3])
+def test_decode_f32_is_the_double_decode_rounded_once(gpu, rows):
+    """relate_hip_decode_f32: the posterior rows in the .post writer's order (IBD0, IBD1, IBD2), the first `rows` of
+    them, as floats -- bit for bit the double posteriors of relate_hip_decode cast to float32, -1 marks included; ragged
+    SNP count (not a multiple of the 16-SNP tile), pair count not a multiple of the 64-pair workgroup, with and
+    without a page-locked destination."""
+    import relate_amd
+    from relate_amd import synth
+    N, M = 30, 4099
+    g, pos, chr_, _ = synth.make_dataset(N, M, n_related=4)
+    gpu.init_globals(g, pos, chr_, dict(pc.options("options.all.pair.txt")))
+    pairs = synth.all_pairs(N)[:131]
+    par = np.tile(np.array([0.05, 0.1, 0.3]), (len(pairs), 1))
+    par[:, 2] = np.linspace(0.05, 0.6, len(pairs))
+    par[::7, 1] = 0.0                                            # k2 == 0 takes decode() instead of decodek2()
+    post, _, ns = gpu.decode(pairs, par)
+    want = post[:, [2, 1, 0][:rows], :].astype(np.float32)
+    got, ns2 = gpu.decode_f32(pairs, par, rows)
+    assert got.dtype == np.float32 and got.shape == (len(pairs), rows, gpu.M)
+    assert np.array_equal(got, want) and np.array_equal(ns, ns2)
+    assert (got == -1).any()
+    pin = relate_amd.pinned_empty((len(pairs), rows, gpu.M), np.float32)
+    got2, _ = gpu.decode_f32(pairs, par, rows, out=pin)
+    assert np.shares_memory(got2, pin) and np.array_equal(got2, want)
+
+
 def test_errors_are_reported_not_swallowed(gpu, prepared):
     import relate_amd
     b = pc.golden()["blocks"][0]
     _init(gpu, prepared, b)
     with pytest.raises(relate_amd.RelateError):
         gpu.like([(0, 100000)], np.zeros((1, 1, 3)))
+    with pytest.raises(relate_amd.RelateError):
+        gpu.decode_f32([(0, 1)], np.array([[0.05, 0.1, 0.3]]), rows=4)
     g, pos, chr_, opt, _ = prepared[(b["data"], b["options"])]
     with pytest.raises(relate_amd.RelateError):
         gpu.init_globals(g, pos, chr_, dict(opt, fixA=1, fixK=0, calcA=0))

@@ -27,3 +27,12 @@ for it in range(6):
           "(posterior copy-back %.2f GB)" % (P, M, "pinned" if pinned else "pageable", dt * 1e3,
                                              (time.perf_counter() - t1) * 1e3, P * M * (E + 2) / dt,
                                              post.nbytes / 1e9), flush=True)
+pin32 = H.post_buffer(P, 2, np.float32)
+for it in range(3):
+    blk = allp[it * P:(it + 1) * P]
+    t0 = time.perf_counter()
+    H.like(blk, par)
+    post, _ = H.decode_f32(blk, np.ascontiguousarray(par[:, 0, :]), 2, out=pin32)
+    dt = time.perf_counter() - t0
+    print("P=%d M=%d float32 rows IBD0+IBD1, pinned: %.1f ms per step = %.3g HMM steps/s (copy-back %.2f GB)" % (
+        P, M, dt * 1e3, P * M * (E + 2) / dt, post.nbytes / 1e9), flush=True)
