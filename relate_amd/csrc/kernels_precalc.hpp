@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "dd_math.hpp"
+
 namespace relate {
 
 static constexpr uint64_t kLoMask = 0x5555555555555555ull;
@@ -125,6 +127,8 @@ __device__ inline int quad_roots(double a, double b, double c, double *x0, doubl
   return 0;
 }
 
+// acos / cos / pow: correctly rounded (dd_math.hpp), so that the roots carry the last bits the host libm gives the
+// reference in all but ~0.1 % of calls -- getHighestId's strict comparison of LD measures is sensitive to them
 __device__ inline int cubic_roots(double a, double b, double c, double *x) {  // src/ld.cpp:139-220
 #pragma clang fp contract(off)
   double q = (a * a - 3 * b);
@@ -151,10 +155,10 @@ __device__ inline int cubic_roots(double a, double b, double c, double *x) {  //
     return 3;
   } else if (CR2 < CQ3) {
     double sqrtQ = sqrt(Q), sqrtQ3 = sqrtQ * sqrtQ * sqrtQ;
-    double theta = acos(R / sqrtQ3), norm = -2 * sqrtQ;
-    double r0 = norm * cos(theta / 3) - a / 3;
-    double r1 = norm * cos((theta + 2.0 * 3.14159265358979323846) / 3) - a / 3;
-    double r2 = norm * cos((theta - 2.0 * 3.14159265358979323846) / 3) - a / 3, tmp;
+    double theta = ddm::acos_cr(R / sqrtQ3), norm = -2 * sqrtQ;
+    double r0 = norm * ddm::cos_cr(theta / 3) - a / 3;
+    double r1 = norm * ddm::cos_cr((theta + 2.0 * 3.14159265358979323846) / 3) - a / 3;
+    double r2 = norm * ddm::cos_cr((theta - 2.0 * 3.14159265358979323846) / 3) - a / 3, tmp;
     if (r0 > r1) { tmp = r0; r0 = r1; r1 = tmp; }
     if (r1 > r2) {
       tmp = r1; r1 = r2; r2 = tmp;
@@ -164,7 +168,7 @@ __device__ inline int cubic_roots(double a, double b, double c, double *x) {  //
     return 3;
   } else {
     double sgnR = (R >= 0 ? 1 : -1);
-    double A = -sgnR * pow(fabs(R) + sqrt(R2 - Q3), 1.0 / 3.0);
+    double A = -sgnR * ddm::pow_cr(fabs(R) + sqrt(R2 - Q3), 1.0 / 3.0);
     double B = Q / A;
     x[0] = A + B - a / 3;
     return 1;
