@@ -32,16 +32,18 @@ for name, dk, ok in CASES:
     kw = dict(dk); N = kw.pop("N"); M = kw.pop("M")
     g, pos, chr_, related = synth.make_dataset(N, M, n_related=3, seed=20240601 + len(name), **kw)
     opt = dict(base, **ok)
+    opt.update(doPar=1, par=[0.05, 0.1, 0.3])   # no optimisation: likelihood, posteriors and path at (a, k2, k1)
     Mref = ref.init(g.astype(np.int32), pos, chr_, opt)
     try:
-        H.init_globals(g, pos, chr_, dict(opt, seed=1, seed_mode=0, doPar=1, par=[0.05, 0.1, 0.3]))
+        H.init_globals(g, pos, chr_, dict(opt, seed=1, seed_mode=0))
         pairs = [(int(r[0]), int(r[1])) for r in related] + [(0, N - 1), (1, N // 2)]
         neq = 0.0
         if opt["ld_adj"]:
             hg, hr = H.hap_global(), ref.hap_global()
             neq = max(float((hg[k] != hr[k]).mean()) for k in ("mea", "pBA", "pBa", "pbA", "pba"))
         worst = 0.0; ok_keep = True; ok_t = True; lk = 0.0
-        res, _, _ = H.sgl(pairs, want_post=False)
+        res, post, path = H.sgl(pairs, want_path=True)   # doPar: likelihood, posteriors and path at par
+        pw = 0.0; pneq = 0; npath = 0
         for n, (i, j) in enumerate(pairs):
             x = ref.sgl(i, j, seed=1)
             kp, tt, S = H.pair_emissions(i, j)
@@ -50,11 +52,15 @@ for name, dk, ok in CASES:
             ok_t &= np.array_equal(tt[idx][1:], x["t"][1:x["m"]])
             if len(idx) == x["m"]:
                 worst = max(worst, float(np.abs(S[:, idx] / x["S"] - 1).max()))
-            lk = max(lk, abs(res[n]["uLike"] / x["uLike"] - 1), abs(res[n]["poLike"] / x["poLike"] - 1))
-        flag = "" if (H.M == Mref and ok_keep and ok_t and worst < 1e-9 and lk < 1e-10) else "   <-- MISMATCH"
+            lk = max(lk, abs(res[n]["uLike"] / x["uLike"] - 1), abs(res[n]["poLike"] / x["poLike"] - 1),
+                     abs(res[n]["negloglik"] / x["nll"] - 1))
+            if len(idx) == x["m"]:
+                pw = max(pw, float(np.abs(post[n][:, idx] - x["post"]).max()))
+                pneq += int((path[n][idx] != x["path"]).sum()); npath += len(idx)
+        flag = "" if (H.M == Mref and ok_keep and ok_t and worst < 1e-9 and lk < 1e-10 and pw < 1e-8 and pneq <= 0.002 * npath) else "   <-- MISMATCH"
         bad += bool(flag)
-        print("%-38s M %d/%d keep %s t %s  S maxrel %.2e  uLike/poLike maxrel %.2e  LD cells differing %.3f %%%s" % (
-            name, H.M, Mref, ok_keep, ok_t, worst, lk, 100 * neq, flag), flush=True)
+        print("%-38s M %d/%d keep %s t %s  S maxrel %.2e  like (u, po, par) maxrel %.2e  post maxabs %.1e  path neq %d/%d  LD cells differing %.3f %%%s" % (
+            name, H.M, Mref, ok_keep, ok_t, worst, lk, pw, pneq, npath, 100 * neq, flag), flush=True)
     finally:
         ref.fini()
 sys.exit(1 if bad else 0)
