@@ -1,4 +1,5 @@
-// Correctly rounded acos, cos and pow for the cubic solve of the LD cells (gsl_poly_solve_cubic, src/ld.cpp:139-220).
+// Correctly rounded acos, cos, pow and log for the LD cells: the cubic solve (gsl_poly_solve_cubic,
+// src/ld.cpp:139-220) and the likelihood that picks among its roots.
 //
 // The reference calls the host libm there.  Its roots, and the LD measures derived from them, carry that libm's
 // last-bit rounding; `getHighestId` then compares LD measures with a strict `>`, so a pair of depths whose measures
@@ -176,6 +177,25 @@ DDM_HD inline double pow_cr(double x, double y) {
   dd e = exp_dd(dd{-l0, 0.0});
   dd l = add(add(mul(e, x), -1.0), l0);  // one Newton step on exp(l) = x: l0 + (x exp(-l0) - 1)
   return exp_dd(mul(l, y)).hi;
+}
+
+// log x for finite x > 0 (the likelihood that picks among the candidate roots, pick_best_p src/ld.cpp)
+DDM_HD inline double log_cr(double x) {
+  DDM_NOCONTRACT
+  if (!(x > 1e-280 && x < 1e280)) return std::log(x);
+  double u = x - 1.0;  // exact for x in [0.5, 2]
+  if (std::fabs(u) < 1e-4) {  // log(1 + u) by its series: the Newton step below loses relative accuracy next to 1
+    dd U = {u, 0.0}, pw = U, sum = U;
+    for (int i = 2; i <= 9; i++) {
+      pw = mul(pw, U);
+      dd t = div(pw, (double)i);
+      sum = (i & 1) ? add(sum, t) : sub(sum, t);
+    }
+    return sum.hi;
+  }
+  double l0 = std::log(x);
+  dd e = exp_dd(dd{-l0, 0.0});
+  return add(add(mul(e, x), -1.0), l0).hi;
 }
 
 }  // namespace ddm

@@ -222,7 +222,7 @@ __device__ inline LdCell ld_cell_from_counts(const int *count) {
     double ex[9] = {u * u, 2. * u * v, v * v, 2. * u * w, 2. * u * x + 2. * v * w, 2. * v * x, w * w, 2. * w * x, x * x};
     double sum = 0;
     for (int q = 0; q < 9; q++)
-      if (count[q] && ex[q] > 0.0) sum += count[q] * log(ex[q]);
+      if (count[q] && ex[q] > 0.0) sum += count[q] * ddm::log_cr(ex[q]);
     if (sum > best) { best = sum; p = pc; }
   }
   double u = j + p * e, v = k + (1.0 - p) * e, w = l + (1.0 - p) * e, x = m + p * e;
