@@ -230,21 +230,18 @@ __global__ void stage_pairs_kernel(const uint64_t *__restrict__ G, int M, int W,
         r.s0 = e[0]; r.s1 = e[1]; r.s2 = e[2];
       } else {
         // slow path: rows r = 0..back-1 <-> r-th previous kept SNP at distance dd = s-1-s_prev (< back2)
-        int best = 0, bestS = -1, nfound = 0;
+        int bestS = -1, nfound = 0;  // bestS: SNP of the first row with the strictly largest measure
         double bv = 0;
         for (int dd = 0; dd < back2 && nfound < back; dd++) {
           int sp = s - 1 - dd;
           if (sp < 0) break;
           if (geno_at(G, W, sp, i1) == 0 || geno_at(G, W, sp, i2) == 0) continue;
           double v = mea[(size_t)dd * (M - 1) + (s - 1)];
-          if (nfound == 0) { bv = v; best = 0; bestS = sp; }
-          else if (v > bv) { bv = v; best = nfound; bestS = sp; }
+          if (nfound == 0 || v > bv) { bv = v; bestS = sp; }
           nfound++;
         }
         if (nfound == 0) { bv = 0; bestS = -1; }
         if (nfound < back && 0.0 > bv) bestS = -1;  // a zero-filled row beyond the window wins (getHighestId, :492)
-        if (back == 1 && nfound > 0) { /* single row: always row 0 (:484-487) */ }
-        (void)best;
         if (bestS < 0) {
           r.s0 = 0; r.s1 = 0; r.s2 = 0;  // hap frequencies of that row are zero -> S2 = 0
         } else {

@@ -645,9 +645,7 @@ struct FitPop {
 };
 
 // fills out[0..P) (and conv_out rows pair_base..) for the P pairs of the staged block
-int fit_block(relate_hip_t h, int P, const int32_t *pairs, long pair_base, const double *starts, relate_fit *out,
-              double *conv_out) {
-  (void)pairs;
+int fit_block(relate_hip_t h, int P, long pair_base, const double *starts, relate_fit *out, double *conv_out) {
   const relate_opts &o = h->o;
   for (int p = 0; p < P; p++) {
     out[p] = relate_fit{};
@@ -847,7 +845,6 @@ int decode_block(relate_hip_t h, int P, const double *params, double *post, int8
   HIPCHK(h, h->dParams.ensure((size_t)3 * P));
   HIPCHK(h, h->dNsnp.ensure(P));
   HIPCHK(h, hipMemcpyAsync(h->dParams.p, params, sizeof(double) * 3 * P, hipMemcpyHostToDevice, h->stream));
-  bool ran = false;
   if (post || post32 || nsnp_out || !copy_back) {
     HIPCHK(h, h->dFwd.ensure((size_t)3 * ((M + 3) / 4) * h->recPitch));
     HIPCHK(h, h->dPost.ensure(post32 ? ((size_t)f32_rows * M * P + 1) / 2 : (size_t)3 * M * P));
@@ -868,9 +865,7 @@ int decode_block(relate_hip_t h, int P, const double *params, double *post, int8
     HIPCHK(h, hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
     h->timings[2] += a;
     h->timings[3] += b;
-    ran = true;
   }
-  (void)ran;
   if (path) {
     HIPCHK(h, h->dBp.ensure((size_t)M * P));
     HIPCHK(h, h->dPath.ensure((size_t)M * P));
@@ -1351,7 +1346,7 @@ int relate_hip_fit(relate_hip_t h, const int32_t *pairs, int P, const double *st
     int pb = (int)std::min<long>((long)lim, P - b0);
     rc = stage_block(h, pairs + 2 * b0, pb);
     if (rc) return rc;
-    rc = fit_block(h, pb, pairs + 2 * b0, b0, starts, out + b0, conv_out);
+    rc = fit_block(h, pb, b0, starts, out + b0, conv_out);
     if (rc) return rc;
   }
   return RELATE_OK;
@@ -1411,7 +1406,7 @@ int relate_hip_run_pairs(relate_hip_t h, const int32_t *pairs, int P, const doub
     int pb = (int)std::min<long>((long)lim, P - b0);
     rc = stage_block(h, pairs + 2 * b0, pb);
     if (rc) return rc;
-    rc = fit_block(h, pb, pairs + 2 * b0, b0, starts, out + b0, nullptr);
+    rc = fit_block(h, pb, b0, starts, out + b0, nullptr);
     if (rc) return rc;
     size_t dlim = pair_block_limit(h, 3 * sizeof(double) + 8, (h->dPost.cap + h->dFwd.cap) * sizeof(double));
     if (dlim > (size_t)pb) dlim = pb;
