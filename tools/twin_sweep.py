@@ -63,4 +63,46 @@ for name, dk, ok in CASES:
             name, H.M, Mref, ok_keep, ok_t, worst, lk, pw, pneq, npath, 100 * neq, flag), flush=True)
     finally:
         ref.fini()
+# ---- the optimisation modes (objective wrappers) with the multi-start fit, pinned seed ---------------------------
+MODES = [
+    ("3 free (a, k2, k1)", dict(calcA=0, fixA=0, fixK=0)),
+    ("fixK2=0: a, k1 free", dict(calcA=0, fixA=0, fixK=1, fixK_val=0.0)),
+    ("fixK2=0 + calcA: k1 free", dict(calcA=1, fixA=0, fixK=1, fixK_val=0.0)),
+    ("fixK2=0.1: a, k1 free", dict(calcA=0, fixA=0, fixK=1, fixK_val=float(np.float32(0.1)))),
+]
+N, M, seed = 24, 3000, 777
+g, pos, chr_, related = synth.make_dataset(N, M, n_related=4, miss=0.005)
+pairs = [(int(r[0]), int(r[1])) for r in related] + [(0, N - 1), (1, N // 2)]
+for name, ok in MODES:
+    opt = dict(base, **ok)
+    Mref = ref.init(g.astype(np.int32), pos, chr_, opt)
+    try:
+        H.init_globals(g, pos, chr_, dict(opt, seed=seed, seed_mode=0))
+        res, post, _ = H.sgl(pairs)
+        on = 0; worst = 0.0; kd = 0.0; pw = 0.0; never_worse = True; obj = 0.0; detail = []
+        for n, (i, j) in enumerate(pairs):
+            x, r = ref.sgl(i, j, seed=seed), res[n]
+            rel = abs(r["negloglik"] / x["nll"] - 1)
+            # the objective itself, at the point where the reference stopped
+            at_ref = H.like([(i, j)], np.array([[[x["a"], x["k2"], x["k1"]]]]))[0, 0]
+            obj = max(obj, abs(at_ref / x["nll"] - 1))
+            if rel > 1e-9:
+                detail.append("      (%d,%d) -logL %.10g / ref %.10g   k1 %.6g / %.6g   a %.5g / %.5g   runs %d / %d" % (
+                    i, j, r["negloglik"], x["nll"], r["k1"], x["k1"], r["a"], x["a"], r["timesRun"], x["timesRun"]))
+            worst = max(worst, rel)
+            never_worse &= r["negloglik"] <= x["nll"] * (1 + 1e-6)
+            if rel <= 1e-9:
+                on += 1
+                kd = max(kd, abs(r["k1"] - x["k1"]), abs(r["k2"] - x["k2"]), abs(r["a"] - x["a"]))
+                idx = np.where(x["keep"] == 1)[0]
+                pw = max(pw, float(np.abs(post[n][:, idx] - x["post"]).max()))
+        flag = "" if (obj < 1e-11 and kd < 1e-6 and pw < 1e-6) else "   <-- MISMATCH"
+        bad += bool(flag)
+        print("fit %-28s objective at the reference's estimate maxrel %.1e; -logL reached maxrel %.2e, never worse %s; on the "
+              "reference's trajectory %d/%d (estimates maxabs %.1e, posteriors %.1e)%s" % (
+                  name, obj, worst, never_worse, on, len(pairs), kd, pw, flag), flush=True)
+        for d in detail:
+            print(d, flush=True)
+    finally:
+        ref.fini()
 sys.exit(1 if bad else 0)
