@@ -27,6 +27,11 @@ CASES = [
     ("N30 M3000 eps 0.05 min 0.1", dict(N=30, M=3000), dict(epsilon=F32(0.05), min=F32(0.1))),
     ("N40 M4000 prune", dict(N=40, M=4000), dict(doPrune=1, prune_val=F32(0.1), back=10, back2=20)),
     ("N16 M1500 copy 0.6", dict(N=16, M=1500, copy_p=0.6), {}),
+    ("N3 M1200", dict(N=3, M=1200), {}),
+    ("N5 M1500 min 0.2", dict(N=5, M=1500), dict(min=F32(0.2))),
+    ("N20 M2000 miss 8%", dict(N=20, M=2000, miss=0.08), {}),
+    ("N20 M1800 one chromosome", dict(N=20, M=1800, nchr=1), {}),
+    ("N300 M600", dict(N=300, M=600), {}),
 ]
 
 
@@ -36,7 +41,7 @@ def test_stage_like_decode_at_a_point(gpu, ref, case):
     name, dk, ok = case
     kw = dict(dk)
     N, M = kw.pop("N"), kw.pop("M")
-    g, pos, chr_, related = synth.make_dataset(N, M, n_related=3, seed=20240601 + len(name), **kw)
+    g, pos, chr_, related = synth.make_dataset(N, M, n_related=min(3, N // 2), seed=20240601 + len(name), **kw)
     opt = dict(pc.options("options.single.pair.txt"), **ok)
     opt.update(doPar=1, par=[0.05, 0.1, 0.3])   # no optimisation: likelihood, posteriors and path at (a, k2, k1)
     Mref = ref.init(g.astype(np.int32), pos, chr_, opt)
@@ -47,6 +52,7 @@ def test_stage_like_decode_at_a_point(gpu, ref, case):
         neq = max(float((hg[k] != hr[k]).mean()) for k in ("mea", "pBA", "pBa", "pbA", "pba"))
         assert neq < 0.005                      # LD cells differing in the last bits (dd_math.hpp)
         pairs = [(int(r[0]), int(r[1])) for r in related] + [(0, N - 1), (1, N // 2)]
+        pairs = sorted({p for p in pairs if p[0] < p[1]})
         res, post, path = gpu.sgl(pairs, want_path=True)
         worst = lk = pw = 0.0
         for n, (i, j) in enumerate(pairs):
