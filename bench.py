@@ -132,6 +132,49 @@ def cpu_baseline(H, opt, E, want_seconds=12.0):
                           dt)}
 
 
+def cpu_baseline_threads(H, opt, E, want_seconds=6.0):
+    """The C port (oracle/: the reference's algorithm restated, re-entrant where the reference keeps its state in
+    statics) on the same bounded sample with one thread per host core of the box's share (pairs are independent):
+    the all-cores companion of cpu_baseline.  ctypes releases the GIL around every call."""
+    import threading
+    import oracleload
+    o = oracleload.Oracle()
+    nt = max(1, min(16, os.cpu_count() or 1))
+    gs, ps, mafs = H.stripped()
+    Ms = min(H.M, 20000)
+    gs = np.ascontiguousarray(gs[:, :Ms])
+    ps, mafs = ps[:Ms].copy(), mafs[:Ms].copy()
+    hap = o.hap_global(gs, opt["back2"], opt["LD"])
+    max_pairs = 880  # individuals 200 .. 1959 in disjoint pairs; ~4 s on 16 threads
+    par = eval_points(max_pairs, E)
+    steps = [0] * nt
+    done = [0] * nt
+    t0 = time.perf_counter()
+
+    def work(k):
+        for p in range(k, max_pairs, nt):
+            i, j = 2 * p + 200, 2 * p + 201
+            st = o.pair_stage(gs, i, j, mafs, ps, opt["epsilon"], 1, opt["back"], opt["back2"], hap)
+            Sk = o.logs(st["S"])
+            for e in range(E):
+                o.like(par[p, e], *Sk, st["t"], 0, opt["alim1"])
+            o.decode(par[p, 0], *Sk, st["t"], 0)
+            steps[k] += st["m"] * (E + 2)
+            done[k] += 1
+            if time.perf_counter() - t0 > want_seconds:
+                break
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(nt)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {"value": sum(steps) / dt, "unit": "pair*SNP HMM steps/s", "cores": nt, "kind": "port",
+            "sample": "%d pairs x first %d SNPs of the same synthetic matrix, E=%d; the C port on %d threads, %.1f s" % (
+                sum(done), Ms, E, nt, dt)}
+
+
 def fit_leg(H, allp, npairs, M):
     """Outside the timed region and not part of `value`: the whole estimation (relate_hip_fit: up to 8 restarts of the
     2-parameter L-BFGS-B search per pair, every objective value a likelihood sweep on the GPU) on the first pairs of the
@@ -290,6 +333,7 @@ def main():
             line["fit"] = fit_leg(H, mine, min(args.fit_pairs, len(mine)), M)
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(H, opt, E)
+            line["cpu_baseline_all_cores"] = cpu_baseline_threads(H, opt, E)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
