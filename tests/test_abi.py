@@ -84,3 +84,20 @@ def test_host_cli_builds_and_fails_loudly_without_gpu(tmp_path):
                        cwd=tmp_path, capture_output=True, text=True, timeout=120)
     assert r.returncode == 1
     assert "no HIP device" in r.stderr or "no CPU fallback" in r.stderr
+
+
+def test_host_buffer_helpers_reject_what_they_do_not_own():
+    """relate_hip_host_free takes only blocks of relate_hip_host_alloc; without a GPU the allocation fails with a
+    message instead of returning pageable memory."""
+    import ctypes as C
+    import relate_amd
+    L = relate_amd.load_library()
+    assert L.relate_hip_host_free(None) == 0
+    assert L.relate_hip_host_free(C.c_void_p(0x1000)) < 0
+    assert b"relate_hip_host_alloc" in L.relate_hip_last_error(None)
+    import torch
+    if not torch.cuda.is_available():
+        p = C.c_void_p(1)
+        assert L.relate_hip_host_alloc(C.byref(p), 1 << 20) < 0
+        assert not p.value
+        assert b"hipHostMalloc" in L.relate_hip_last_error(None)
