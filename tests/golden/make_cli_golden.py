@@ -11,6 +11,8 @@ on the fixture data.  Run here, in the build container; the outputs are committe
           and 25 among them, 2 % missing; written here by tests/test_bed_ingest.py:synthetic, seed 6, and committed):
           options.all.pair.txt -plink syn6        (doBimFile filter, (chr,pos) sort, MAF filter: dumps; 120 pairs)
     c7_*  the same files, options.linkage.txt -plink syn6 -d syn6.keep (all 16 kept): pruning on top, 1-parameter fit
+    c8_*  flat files data/syn8.geno/.pos/.chr (12 individuals x 800 SNPs of 5 chromosomes, columns in shuffled order,
+          3 % missing; numpy default_rng(8), committed): options.linkage.txt -g -p -c -d syn8.keep  (mysort on the matrix)
 """
 import os
 import shutil
@@ -43,6 +45,32 @@ if not os.path.exists(DATA + "/syn6.bed"):
             shutil.copy(prefix + ext, DATA + "/syn6" + ext)
     with open(DATA + "/syn6.keep", "w") as fh:
         fh.write(" ".join(["1"] * 16) + "\n")
+if not os.path.exists(DATA + "/syn8.geno"):
+    import numpy as np
+    rng = np.random.default_rng(8)
+    n, m = 12, 800
+    chrom = np.sort(rng.integers(1, 6, size=m))
+    bp = np.concatenate([np.sort(rng.choice(np.arange(1, 40_000_000), size=int((chrom == c).sum()), replace=False))
+                         for c in range(1, 6)])
+    freq = rng.uniform(0.1, 0.9, size=m)
+    hap = rng.random((2 * n, m)) < freq
+    for s_ in range(1, m):                      # LD: copy the previous SNP's allele with probability 0.4
+        cp = rng.random(2 * n) < 0.4
+        hap[cp, s_] = hap[cp, s_ - 1]
+    geno = 1 + hap[0::2].astype(int) + hap[1::2].astype(int)
+    geno[rng.random(geno.shape) < 0.03] = 0
+    order = rng.permutation(m)
+    with open(DATA + "/syn8.geno", "w") as fh:
+        for i in range(n):
+            fh.write(" ".join(str(v) for v in geno[i, order]) + "\n")
+    with open(DATA + "/syn8.pos", "w") as fh:
+        fh.write(" ".join("%.6f" % (bp[c] / 1e6) for c in order) + "\n")
+    with open(DATA + "/syn8.chr", "w") as fh:
+        fh.write(" ".join(str(chrom[c]) for c in order) + "\n")
+    with open(DATA + "/syn8.keep", "w") as fh:
+        fh.write(" ".join(["1"] * n) + "\n")
+RUNS["c8"] = ["-o", DATA + "/options.linkage.txt", "-g", DATA + "/syn8.geno", "-p", DATA + "/syn8.pos", "-c",
+              DATA + "/syn8.chr", "-d", DATA + "/syn8.keep", "-post", "out.post", "-k", "out.k"]
 RUNS["c6"] = ["-o", DATA + "/options.all.pair.txt", "-plink", DATA + "/syn6", "-post", "out.post", "-k", "out.k"]
 RUNS["c7"] = ["-o", DATA + "/options.linkage.txt", "-plink", DATA + "/syn6", "-d", DATA + "/syn6.keep", "-post", "out.post",
               "-k", "out.k"]
@@ -54,7 +82,7 @@ for name, args in RUNS.items():
         subprocess.run([REF] + args, cwd=td, env=env, check=True, stdout=subprocess.DEVNULL)
         for f in ("out.post", "out.k", "stripped.geno", "stripped.pos", "stripped.chr", "keep.index"):
             src = os.path.join(td, f)
-            if name in ("c3", "c6", "c7") and f == "out.post":
+            if name in ("c3", "c6", "c7", "c8") and f == "out.post":
                 continue  # 0.5 MB of posteriors at chaotic estimates: not a usable pin
             if os.path.exists(src):
                 shutil.copy(src, os.path.join(OUT, "%s_%s" % (name, f)))
