@@ -99,7 +99,7 @@ struct LaneC {
   double na, nak1;      // -a, -a*k1
   double nk1;           // -k1
   double k0, k1, k2;
-  double r10, r12, rs;  // k0/k1, k2/k1 (both 1 when k1 == 0), and their sum
+  double r10, r12;      // k0/k1, k2/k1 (both 1 when k1 == 0)
   double ikm1;          // 1/(k1-1); 0 when k1 == 1
   double g2, g3, g4, g5, g6;
   double tlim0, tlim1;  // t below which |a t| < 2^-7 / 2^-4
@@ -115,7 +115,6 @@ __device__ inline LaneC make_lane(double a, double k2, double k1, double k0) {
   C.tlim1 = 0x1p-4 / a;
   C.ikm1 = (k1 == 1) ? 0.0 : 1.0 / (k1 - 1);
   if (k1 == 0) { C.r10 = 1; C.r12 = 1; } else { C.r10 = k0 / k1; C.r12 = k2 / k1; }
-  C.rs = C.r10 + C.r12;
   double s = 1.0;               // 1 + k1 + ... + k1^(j-2)
   C.g2 = k1 * s * (1.0 / 2);
   s = __builtin_fma(s, k1, 1.0);
@@ -164,7 +163,7 @@ __device__ inline Trans trans_at(const LaneC &C, double t) {
 
 // v <- (v T) o S for NV row vectors sharing one T (forward step); DR = double recombination (dbl_recom, :501-507)
 //   new0 = f0 + u (f1 r10 - f0) + w (f2 k0 - f0 k2)
-//   new1 = f1 + u (f0 + f2 - f1 (r10 + r12))
+//   new1 = f1 + u (f0 + f2 - f1 (r10 + r12)) = f1 - u (A + D),  A = f1 r10 - f0,  D = f1 r12 - f2
 //   new2 = f2 + u (f1 r12 - f2) - w (f2 k0 - f0 k2)
 template <int NV, bool DR, int TIER>
 __device__ inline void fwd_step(const LaneC &C, const EmisRec &r, double (&x)[NV][3]) {
@@ -187,10 +186,9 @@ __device__ inline void fwd_step(const LaneC &C, const EmisRec &r, double (&x)[NV
     double f0 = x[v][0], f1 = x[v][1], f2 = x[v][2];
     double A = __builtin_fma(f1, C.r10, -f0);
     double B = __builtin_fma(f2, C.k0, -(f0 * C.k2));
-    double Cc = __builtin_fma(-f1, C.rs, f0 + f2);
     double D = __builtin_fma(f1, C.r12, -f2);
     double u0 = __builtin_fma(T.w, B, __builtin_fma(T.u, A, f0));
-    double u1 = __builtin_fma(T.u, Cc, f1);
+    double u1 = __builtin_fma(-T.u, A + D, f1);  // f0 + f2 - f1 (r10 + r12) = -(A + D): the columns of T - I sum to zero
     double u2 = __builtin_fma(-T.w, B, __builtin_fma(T.u, D, f2));
     x[v][0] = u0 * r.s0;
     x[v][1] = u1 * r.s1;
