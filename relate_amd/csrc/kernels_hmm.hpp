@@ -48,6 +48,12 @@ __device__ inline double em_tiny(double x, double xx) {  // |x| < 2^-7: x + x^2 
   p = __builtin_fma(x, p, 0.5);
   return __builtin_fma(xx, p, x);
 }
+__device__ inline double em_tiny5(double x, double xx) {  // |x| < 2^-8: terms through x^5/120, abs. err < 5e-18
+  double p = __builtin_fma(x, 1.0 / 120, 1.0 / 24);
+  p = __builtin_fma(x, p, 1.0 / 6);
+  p = __builtin_fma(x, p, 0.5);
+  return __builtin_fma(xx, p, x);
+}
 __device__ inline double em_small(double x) {  // |x| < 2^-4: Taylor through x^10/10!
   double p = 1.0 / 3628800;
   p = __builtin_fma(x, p, 1.0 / 362880);
@@ -85,7 +91,9 @@ __device__ inline double em_general(double x) {  // any x <= 0: exp by range red
 
 // Tiers of the per-step exponentials: 0 = |a t| < 2^-7, 1 = |a t| < 2^-4, 2 = any t.  The tier is chosen per wave and
 // per group of records (lanes of a wave sit on the same SNPs, so t is uniform up to per-pair dropped SNPs and |a t|
-// differs only through a): straight-line code for the whole group, no per-step branch.
+// differs only through a): straight-line code for the whole group, no per-step branch.  The likelihood sweeps (VALU-bound)
+// have a tier -1 below tier 0: |a t| < 2^-8, where both series stop one term earlier (absolute truncation error
+// < 5e-18 in u and < 2.5e-17 in w, a tenth of an ulp of the vector they are added to).
 
 // ---- per-lane constants, hoisted out of the SNP loop (src/relateHMM.cpp:1440-1490) -------------------------
 // With m1 = expm1(-a t), m2 = expm1(-a k1 t), x = -a t:
@@ -103,6 +111,7 @@ struct LaneC {
   double ikm1;          // 1/(k1-1); 0 when k1 == 1
   double g2, g3, g4, g5, g6;
   double tlim0, tlim1;  // t below which |a t| < 2^-7 / 2^-4
+  double tlimm;         // ... < 2^-8
 };
 
 __device__ inline LaneC make_lane(double a, double k2, double k1, double k0) {
@@ -111,6 +120,7 @@ __device__ inline LaneC make_lane(double a, double k2, double k1, double k0) {
   C.nak1 = -a * k1;
   C.nk1 = -k1;
   C.k0 = k0; C.k1 = k1; C.k2 = k2;
+  C.tlimm = 0x1p-8 / a;
   C.tlim0 = 0x1p-7 / a;
   C.tlim1 = 0x1p-4 / a;
   C.ikm1 = (k1 == 1) ? 0.0 : 1.0 / (k1 - 1);
@@ -132,7 +142,7 @@ __device__ inline LaneC make_lane(double a, double k2, double k1, double k0) {
 template <int TIER>
 __device__ inline double m1_at(const LaneC &C, double t) {
   double x = C.na * t;
-  return TIER == 0 ? em_tiny(x, x * x) : (TIER == 1 ? em_small(x) : em_general(x));
+  return TIER <= 0 ? em_tiny(x, x * x) : (TIER == 1 ? em_small(x) : em_general(x));
 }
 
 // the two numbers that carry the distance t into the transition matrix
@@ -143,7 +153,14 @@ template <int TIER>
 __device__ inline Trans trans_at(const LaneC &C, double t) {
   Trans T;
   double x = C.na * t;
-  if (TIER == 0) {
+  if (TIER < 0) {
+    double xx = x * x;
+    T.u = C.nk1 * em_tiny5(x, xx);
+    double q = __builtin_fma(x, C.g5, C.g4);
+    q = __builtin_fma(x, q, C.g3);
+    q = __builtin_fma(x, q, C.g2);
+    T.w = xx * q;
+  } else if (TIER == 0) {
     double xx = x * x;
     T.u = C.nk1 * em_tiny(x, xx);
     double q = __builtin_fma(x, C.g6, C.g5);
@@ -236,12 +253,13 @@ __device__ inline bool lane_params(const double *__restrict__ params, int l, dou
 __device__ inline bool rec_dropped(const EmisRec &r) { return __builtin_signbit(r.t); }
 
 // wave-uniform tier of a group of N records: 0 if every lane has |a t| < 2^-7 for all of them, 1 if < 2^-4, else 2
-template <int N>
+template <int N, bool LOW = false>
 __device__ inline int group_tier(const LaneC &C, const EmisRec (&R)[N]) {
   double tmax = R[0].t;
 #pragma unroll
   for (int u = 1; u < N; u++) tmax = __builtin_fmax(tmax, R[u].t);
-  if (__builtin_amdgcn_ballot_w64(!(tmax < C.tlim0)) == 0) return 0;
+  if (__builtin_amdgcn_ballot_w64(!(tmax < C.tlim0)) == 0)
+    return (LOW && __builtin_amdgcn_ballot_w64(!(tmax < C.tlimm)) == 0) ? -1 : 0;
   if (__builtin_amdgcn_ballot_w64(!(tmax < C.tlim1)) == 0) return 1;
   return 2;
 }
@@ -253,8 +271,9 @@ __device__ inline void fwd_group_t(const LaneC &C, const EmisRec (&R)[kGroup], d
 }
 template <int NV, bool DR>
 __device__ inline void fwd_group(const LaneC &C, const EmisRec (&R)[kGroup], double (&x)[NV][3]) {
-  int tier = group_tier<kGroup>(C, R);
-  if (tier == 0) fwd_group_t<NV, DR, 0>(C, R, x);
+  int tier = group_tier<kGroup, !DR>(C, R);
+  if (tier < 0) fwd_group_t<NV, DR, -1>(C, R, x);
+  else if (tier == 0) fwd_group_t<NV, DR, 0>(C, R, x);
   else if (tier == 1) fwd_group_t<NV, DR, 1>(C, R, x);
   else fwd_group_t<NV, DR, 2>(C, R, x);
 }
