@@ -357,6 +357,149 @@ like_kernel(const EmisRec *__restrict__ rec, int M, int RP, const int32_t *__res
   out[l] = -(log(tot) + (double)ex[0] * kLn2);
 }
 
+// The same records from the last row down (the backward half of the two-sided likelihood): groups of kGroup rows
+// [base, base + kGroup) are handed over in descending order of base, then single rows down to sb.
+template <int NBUF, class FG, class FT>
+__device__ inline void stream_records_rev(const EmisRec *__restrict__ col, size_t stride, int sb, int se, FG &&on_group,
+                                          FT &&on_tail) {
+  constexpr int span = NBUF * kGroup;
+  int s = se;  // rows [sb, s) are still to do
+  EmisRec buf[NBUF][kGroup];
+  if (s - span >= sb) {
+#pragma unroll
+    for (int j = 0; j < NBUF; j++)
+#pragma unroll
+      for (int u = 0; u < kGroup; u++) buf[j][u] = col[(size_t)(s - (j + 1) * kGroup + u) * stride];
+  }
+  for (; s - span >= sb; s -= span) {
+#pragma unroll
+    for (int j = 0; j < NBUF; j++) {
+      on_group(buf[j], s - (j + 1) * kGroup);
+      // refill one ring turn further down; clamped to row 0 so that a prefetch below the range (discarded) stays valid
+#pragma unroll
+      for (int u = 0; u < kGroup; u++) buf[j][u] = col[(size_t)max(s - span - (j + 1) * kGroup + u, 0) * stride];
+    }
+  }
+  for (s = s - 1; s >= sb; s--) on_tail(col[(size_t)s * stride], s);
+}
+
+template <bool DR, int TIER>
+__device__ inline void bwd_group_t(const LaneC &C, const EmisRec (&R)[kGroup], double &b0, double &b1, double &b2) {
+#pragma unroll
+  for (int u = kGroup - 1; u >= 0; u--) bwd_step<DR, TIER>(C, R[u], b0, b1, b2);
+}
+
+// K5, two-sided.  The likelihood is alpha_mid . beta_mid for any cut: workgroups [0, nb) sweep rows [0, mid) forward
+// from the start vector k, workgroups [nb, 2 nb) sweep rows [mid, M) backward from the vector of ones, and
+// like_join_kernel takes the dot product.  Twice the lanes at half the length for the same arithmetic: a launch of
+// up to one wave per SIMD (a serial chain per lane, 62 % of the issue rate) becomes one of up to two.
+// part: 12 x nlp doubles (alpha[3], its three exponents, beta[3], its three exponents), nlp = lanes padded to 256.
+//
+// What the single sweep gets for free and this one must look after: a component that does not reach the likelihood
+// may outgrow, over 10^5 SNPs, the ones that do by more than the exponent range.
+//  * A state with k_x == 0 is never entered (T_yx = 0 for every y) and never held (alpha_x == 0): its beta is cleared
+//    at the start and at every rescaling (k = (0, 1, 0), the poLike lane, gave beta_1 = 0 without).
+//  * k1 == 0 makes T the identity (not under double recombination): states 0 and 2 are two separate chains, alpha_0 may win the first half and beta_2
+//    the second.  Such a lane rescales every component on its own exponent (exact: the components never mix).
+// Every other lane mixes its states at every step (T_xy >= k_y w > 0), which bounds the ratios, and uses one exponent.
+struct HalfNorm {
+  double z0, z1, z2;  // 0 for a state with k_x == 0
+  bool iso;           // k1 == 0: independent components
+  int e0 = 0, e1 = 0, e2 = 0;
+  __device__ HalfNorm(double k0, double k1, double k2, bool dr)  // the double-recombination T mixes 0 and 2 whatever k1 is
+      : z0(k0 == 0 ? 0.0 : 1.0), z1(k1 == 0 ? 0.0 : 1.0), z2(k2 == 0 ? 0.0 : 1.0), iso(!dr && k1 == 0) {}
+  __device__ inline void operator()(double &x0, double &x1, double &x2) {
+    x0 *= z0; x1 *= z1; x2 *= z2;
+    if (iso) {
+      int f0 = x0 > 0 ? __builtin_amdgcn_frexp_exp(x0) : 0, f2 = x2 > 0 ? __builtin_amdgcn_frexp_exp(x2) : 0;
+      x0 = __builtin_amdgcn_ldexp(x0, -f0);
+      x2 = __builtin_amdgcn_ldexp(x2, -f2);
+      e0 += f0; e2 += f2;
+    } else {
+      int e = rescale3(x0, x1, x2);
+      e0 += e; e1 += e; e2 += e;
+    }
+  }
+  __device__ inline void store(double *__restrict__ q, size_t nlp, double x0, double x1, double x2) const {
+    q[0] = x0; q[nlp] = x1; q[2 * nlp] = x2;
+    q[3 * nlp] = (double)e0; q[4 * nlp] = (double)e1; q[5 * nlp] = (double)e2;
+  }
+};
+
+template <bool DR, int NBUF>
+__global__ void __launch_bounds__(256)
+like_halves_kernel(const EmisRec *__restrict__ rec, int M, int RP, const int32_t *__restrict__ lane_pair,
+                   const double *__restrict__ params, int nlanes, int nlp, double alim1, double *__restrict__ part) {
+  const int nb = nlp / 256;
+  const bool back = (int)blockIdx.x >= nb;
+  int l = ((int)blockIdx.x - (back ? nb : 0)) * 256 + threadIdx.x;
+  if (l >= nlanes) return;
+  double a, k2, k1, k0;
+  if (!lane_params(params, l, alim1, true, a, k2, k1, k0)) return;  // like_join_kernel rejects the lane
+  LaneC C = make_lane(a, k2, k1, k0);
+  const int mid = (M / 2) & ~(kGroup - 1);
+  const int lp = lane_pair[l];
+  HalfNorm norm(k0, k1, k2, DR);
+  if (!back) {
+    double x[1][3] = {{k0, k1, k2}};
+    stream_records<NBUF>(
+        rec + lp, (size_t)RP, 0, mid, M,
+        [&](const EmisRec(&R)[kGroup], int s) {
+          fwd_group<1, DR>(C, R, x);
+          if ((s & 12) == 12) norm(x[0][0], x[0][1], x[0][2]);  // every fourth group, as sweep()
+        },
+        [&](const EmisRec &r, int s) {
+          fwd_step<1, DR, 2>(C, r, x);
+          if ((s & 7) == 7) norm(x[0][0], x[0][1], x[0][2]);
+        });
+    norm(x[0][0], x[0][1], x[0][2]);
+    norm.store(part + l, (size_t)nlp, x[0][0], x[0][1], x[0][2]);
+    return;
+  }
+  double b0 = 1, b1 = 1, b2 = 1;
+  stream_records_rev<NBUF>(
+      rec + lp, (size_t)RP, mid, M,
+      [&](const EmisRec(&R)[kGroup], int s) {
+        int tier = group_tier<kGroup, !DR>(C, R);
+        if (tier < 0) bwd_group_t<DR, -1>(C, R, b0, b1, b2);
+        else if (tier == 0) bwd_group_t<DR, 0>(C, R, b0, b1, b2);
+        else if (tier == 1) bwd_group_t<DR, 1>(C, R, b0, b1, b2);
+        else bwd_group_t<DR, 2>(C, R, b0, b1, b2);
+        if ((s & 12) == 0) norm(b0, b1, b2);
+      },
+      [&](const EmisRec &r, int s) {
+        bwd_step<DR, 2>(C, r, b0, b1, b2);
+        if ((s & 7) == 0) norm(b0, b1, b2);
+      });
+  norm(b0, b1, b2);
+  norm.store(part + (size_t)6 * nlp + l, (size_t)nlp, b0, b1, b2);
+}
+
+__global__ void __launch_bounds__(256)
+like_join_kernel(const double *__restrict__ part, const double *__restrict__ params, int nlanes, int nlp, double alim1,
+                 double *__restrict__ out) {
+  int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= nlanes) return;
+  double a, k2, k1, k0;
+  if (!lane_params(params, l, alim1, true, a, k2, k1, k0)) { out[l] = 10000000.0; return; }
+  double pr[3];
+  int ex[3], emax = -2147483647;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    pr[c] = part[(size_t)c * nlp + l] * part[(size_t)(6 + c) * nlp + l];
+    ex[c] = (int)part[(size_t)(3 + c) * nlp + l] + (int)part[(size_t)(9 + c) * nlp + l];
+    if (pr[c] > 0 && ex[c] > emax) emax = ex[c];
+  }
+  double tot = 0;
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+    if (pr[c] > 0) tot += ldexp(pr[c], max(ex[c] - emax, -2000));
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+    if (!(pr[c] >= 0)) tot = pr[c];  // NaN from a broken recursion propagates, as in the single sweep
+  out[l] = -(log(tot) + (double)emax * kLn2);
+}
+
 // Chunk products.  Thread (chunk c, lane l) at index at = c * nlp + l (nlp = lanes padded to 256): rows X[i][.]
 // (i = unit start vector) with exponents e[i]:
 //   alpha_end[y] = sum_i alpha_start[i] X[i][y] 2^{e[i]}        beta_start[i] = 2^{e[i]} sum_y X[i][y] beta_end[y]

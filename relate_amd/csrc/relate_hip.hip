@@ -319,6 +319,25 @@ int launch_like(relate_hip_t h, int P, int nl) {
   if (nchunk == 1) {
     // ring depth by the waves per SIMD this launch can fill (kernels_hmm.hpp, like_kernel)
     const long simd_lanes = 256L * 4 * 64;
+    // Up to one wave per SIMD: the two-sided sweep instead (twice the lanes, half the length, like_halves_kernel).
+    // RELATE_LIKE_TWO_SIDED=0 keeps the single sweep (tests, tuning).
+    static const bool two_sided = [] { const char *e = getenv("RELATE_LIKE_TWO_SIDED"); return !(e && atoi(e) == 0); }();
+    if (two_sided && nl <= simd_lanes && h->M >= 64) {
+      int nlp = pad256(nl);
+      HIPCHK(h, h->dCm.ensure((size_t)12 * nlp));
+      dim3 grid((unsigned)(2 * (nlp / 256)));
+      if (dr)
+        hipLaunchKernelGGL((like_halves_kernel<true, 4>), grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch,
+                           h->dLanePair.p, h->dParams.p, nl, nlp, h->o.alim[1], h->dCm.p);
+      else
+        hipLaunchKernelGGL((like_halves_kernel<false, 4>), grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch,
+                           h->dLanePair.p, h->dParams.p, nl, nlp, h->o.alim[1], h->dCm.p);
+      HIPCHK(h, hipGetLastError());
+      hipLaunchKernelGGL(like_join_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, h->dCm.p, h->dParams.p, nl,
+                         nlp, h->o.alim[1], h->dOut.p);
+      HIPCHK(h, hipGetLastError());
+      return 0;
+    }
     const int nbuf = nl <= simd_lanes ? 6 : (nl <= 2 * simd_lanes ? 4 : 2);
     dim3 grid(blocks_for(nl, 256)), block(256);
 #define LAUNCH_LIKE(DR, NB)                                                                                        \

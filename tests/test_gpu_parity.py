@@ -264,12 +264,24 @@ def test_scale_properties_chunked_equals_unchunked(gpu, oracle):
     np.testing.assert_allclose(bvals[:3, 0], a[:, 0], rtol=1e-12)
     np.testing.assert_allclose(bvals[:3, 1], a[:, 1], rtol=1e-12)
     assert np.ptp(bvals[:, 2:], axis=1).max() == 0                            # identical lanes, identical values
-    # the single sweep has three builds by ring depth (one / two / three or more waves per SIMD): 63 000 and 105 000
-    # lanes take the other two; the arithmetic is the same instruction sequence, so the values are bit-identical
-    for npairs in (900, 1500):
-        v = gpu.like(many[:npairs], big[:npairs])
-        assert gpu.last_chunks()[0] == 1
-        assert np.array_equal(v, bvals[:npairs])
+    # the single sweep has builds by ring depth (two / three or more waves per SIMD): 105 000 lanes take the other
+    # one; the arithmetic is the same instruction sequence, so the values are bit-identical.  63 000 lanes (up to one
+    # wave per SIMD) take the two-sided sweep (forward half . backward half): equal to rounding
+    v = gpu.like(many[:1500], big[:1500])
+    assert gpu.last_chunks()[0] == 1
+    assert np.array_equal(v, bvals[:1500])
+    v = gpu.like(many[:900], big[:900])
+    assert gpu.last_chunks()[0] == 1
+    np.testing.assert_allclose(v, bvals[:900], rtol=1e-13)
+    assert np.ptp(v[:, 2:], axis=1).max() == 0
+    # ... also where states cannot be entered (k with exact zeros: the backward vector of such a state is cleared)
+    edge = np.array([(0.05, 0.0, 1.0), (0.05, 0.0, 0.0), (0.05, 1.0, 0.0), (0.05, 0.0, 0.4), (0.05, 0.3, 0.0),
+                     (0.05, 0.6, 0.4)])
+    eb = np.broadcast_to(edge, (len(many), len(edge), 3)).copy()
+    wide = gpu.like(many, eb)[:900]                                           # 36 000 lanes x ... -> chunked or single
+    two = gpu.like(many[:900], np.tile(eb[:900], (1, 12, 1)))                 # 64 800 lanes -> two-sided
+    assert np.isfinite(two).all()
+    np.testing.assert_allclose(two[:, :len(edge)], wide, rtol=1e-13)
     perm = np.random.default_rng(1).permutation(len(many))[:500]
     c = gpu.like(many[perm], big[perm][:, :2])
     # 1000 lanes take the SNP-chunked route, 420k lanes the single sweep: equal to rounding, not bit for bit
@@ -291,6 +303,28 @@ def test_scale_properties_chunked_equals_unchunked(gpu, oracle):
     np.testing.assert_allclose(a[0], want, rtol=1e-10)
     idx = np.where(st["keep"] == 1)[0]
     np.testing.assert_allclose(post[0][:, idx], oracle.decode(par[0], *Sk, st["t"], 0), atol=1e-8)
+
+
+def test_two_sided_likelihood_under_double_recombination(gpu):
+    """The two-sided sweep (launches of up to one wave per SIMD) against the SNP-chunked route under the double
+    recombination model, where k1 == 0 does not separate states 0 and 2: same values to rounding, exact zeros in k
+    included."""
+    from relate_amd import synth
+    N, M = 120, 60000
+    g, pos, chr_, _ = synth.make_dataset(N, M, n_related=10)
+    opt = dict(pc.options("options.all.pair.txt"))
+    opt["double_recom"] = 1
+    gpu.init_globals(g, pos, chr_, opt)
+    allp = synth.all_pairs(N)
+    edge = np.array([(0.05, 0.1, 0.3), (0.05, 0.0, 1.0), (0.05, 0.0, 0.0), (0.05, 1.0, 0.0), (0.05, 0.0, 0.4),
+                     (0.05, 0.3, 0.0), (0.05, 0.6, 0.4), (0.02, 0.25, 0.5)])
+    few = allp[:1000]
+    ref = gpu.like(few, np.broadcast_to(edge, (len(few), len(edge), 3)).copy())   # 8 000 lanes: chunked
+    assert gpu.last_chunks()[0] > 1
+    two = gpu.like(few, np.tile(np.broadcast_to(edge, (len(few), len(edge), 3)), (1, 8, 1)).copy())  # 64 000 lanes
+    assert gpu.last_chunks()[0] == 1
+    assert np.isfinite(two).all()
+    np.testing.assert_allclose(two[:, :len(edge)], ref, rtol=1e-13)
 
 
 def test_result_copy_paths_agree(gpu):
