@@ -41,11 +41,11 @@ def algorithmic_bytes(like_chunks, decode_chunks):
 
 
 # FP64 VALU instructions per lane-step of the likelihood kernels, counted by rocprofv3 (SQ_INSTS_VALU / wave-steps,
-# profiles/r01_pmc_sq.json): single sweep 29.0, chunk-product sweep (three row vectors) 56.5 at this data set's SNP
+# profiles/r01_pmc_sq.json): single sweep 27.8 (derived), chunk-product sweep (three row vectors) 55.2 at this data set's SNP
 # density (four fifths of the record groups take the shortest series).  Peak = one FP64
 # instruction per lane per 4 cycles per SIMD at the 2.4 GHz boost clock; under this load the part holds 1.6-1.7 GHz
 # (GRBM_GUI_ACTIVE / 8 / kernel time) and a pure FMA stream measures 28.8e12 lane-FMA/s (tools/ubench/fp64_ops.hip).
-VALU_PER_STEP = {1: 29.0, 3: 56.5}
+VALU_PER_STEP = {1: 27.8, 3: 55.2}
 FP64_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9  # 39.3e12 at the 2.4 GHz boost clock
 
 

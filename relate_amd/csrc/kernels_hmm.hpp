@@ -103,6 +103,8 @@ __device__ inline double em_general(double x) {  // any x <= 0: exp by range red
 // The series form of w has no cancellation and no division; it is used in tier 0 (terms through x^6, absolute
 // truncation error < 3e-18) and the closed form in the other tiers.  k1 == 1 forces k0 = k2 = 0, so T02 = T20 = 0 as
 // the reference sets them (:1461-1489); k1 == 0 gives u = w = 0.
+__device__ inline int hi_word(double x) { return (int)(__builtin_bit_cast(long long, x) >> 32); }
+
 struct LaneC {
   double na, nak1;      // -a, -a*k1
   double nk1;           // -k1
@@ -110,8 +112,7 @@ struct LaneC {
   double r10, r12;      // k0/k1, k2/k1 (both 1 when k1 == 0)
   double ikm1;          // 1/(k1-1); 0 when k1 == 1
   double g2, g3, g4, g5, g6;
-  double tlim0, tlim1;  // t below which |a t| < 2^-7 / 2^-4
-  double tlimm;         // ... < 2^-8
+  int hlim0, hlim1, hlimm;  // high words of the t below which |a t| < 2^-7 / 2^-4 / 2^-8 (group_tier)
 };
 
 __device__ inline LaneC make_lane(double a, double k2, double k1, double k0) {
@@ -120,9 +121,9 @@ __device__ inline LaneC make_lane(double a, double k2, double k1, double k0) {
   C.nak1 = -a * k1;
   C.nk1 = -k1;
   C.k0 = k0; C.k1 = k1; C.k2 = k2;
-  C.tlimm = 0x1p-8 / a;
-  C.tlim0 = 0x1p-7 / a;
-  C.tlim1 = 0x1p-4 / a;
+  C.hlimm = hi_word(0x1p-8 / a);
+  C.hlim0 = hi_word(0x1p-7 / a);
+  C.hlim1 = hi_word(0x1p-4 / a);
   C.ikm1 = (k1 == 1) ? 0.0 : 1.0 / (k1 - 1);
   if (k1 == 0) { C.r10 = 1; C.r12 = 1; } else { C.r10 = k0 / k1; C.r12 = k2 / k1; }
   double s = 1.0;               // 1 + k1 + ... + k1^(j-2)
@@ -253,14 +254,18 @@ __device__ inline bool lane_params(const double *__restrict__ params, int l, dou
 __device__ inline bool rec_dropped(const EmisRec &r) { return __builtin_signbit(r.t); }
 
 // wave-uniform tier of a group of N records: 0 if every lane has |a t| < 2^-7 for all of them, 1 if < 2^-4, else 2
+// (-1 below 2^-8 when LOW).  t is +0.0, -0.0 (dropped) or positive, so its order is the order of its high word as a
+// signed integer: the comparison runs on high words (3 integer max + compares instead of 7 canonicalising v_max_f64
+// per group); a t whose high word equals the limit's counts as above it, which only ever picks the more careful tier.
+// NaN has the largest high word and goes to tier 2, where it propagates.
 template <int N, bool LOW = false>
 __device__ inline int group_tier(const LaneC &C, const EmisRec (&R)[N]) {
-  double tmax = R[0].t;
+  int hmax = hi_word(R[0].t);
 #pragma unroll
-  for (int u = 1; u < N; u++) tmax = __builtin_fmax(tmax, R[u].t);
-  if (__builtin_amdgcn_ballot_w64(!(tmax < C.tlim0)) == 0)
-    return (LOW && __builtin_amdgcn_ballot_w64(!(tmax < C.tlimm)) == 0) ? -1 : 0;
-  if (__builtin_amdgcn_ballot_w64(!(tmax < C.tlim1)) == 0) return 1;
+  for (int u = 1; u < N; u++) hmax = max(hmax, hi_word(R[u].t));
+  if (__builtin_amdgcn_ballot_w64(!(hmax < C.hlim0)) == 0)
+    return (LOW && __builtin_amdgcn_ballot_w64(!(hmax < C.hlimm)) == 0) ? -1 : 0;
+  if (__builtin_amdgcn_ballot_w64(!(hmax < C.hlim1)) == 0) return 1;
   return 2;
 }
 
