@@ -27,6 +27,7 @@
 // chunk_matrix_kernel forms every chunk's product (three row vectors with their own power-of-two exponents) and a
 // short combine kernel folds the C products per lane.  The exponentials and T are shared by the three rows, so a
 // chunked step costs ~2x a plain one.  A workgroup is 256 lanes of ONE chunk, so loop bounds are scalar.
+// Between the two, a launch of up to one wave per SIMD runs two-sided (like_halves_kernel): forward half . backward half.
 //
 // Memory.  Every lane streams its column of records, 4 records (128 B) per group, double-buffered in registers.
 #pragma once
