@@ -252,6 +252,13 @@ __device__ inline bool lane_params(const double *__restrict__ params, int l, dou
   return !(reject && (k2 < 0 || k1 < 0 || k0 < 0 || k2 > 1 || a > alim1));  // like()'s rejection, :1436
 }
 
+// lane -> pair of the staged block: an explicit list (the optimiser's lanes), or lane / div (E points per pair in order)
+struct LaneMap {
+  const int32_t *pair;
+  int div;
+  __device__ inline int operator()(int l) const { return pair ? pair[l] : l / div; }
+};
+
 __device__ inline bool rec_dropped(const EmisRec &r) { return __builtin_signbit(r.t); }
 
 // wave-uniform tier of a group of N records: 0 if every lane has |a t| < 2^-7 for all of them, 1 if < 2^-4, else 2
@@ -349,7 +356,7 @@ __device__ inline void sweep(const EmisRec *__restrict__ rec, int RP, int lp, in
 // on NBUF 2 (158 VGPRs), where a deeper ring would cost the third wave.
 template <bool DR, int NBUF>
 __global__ void __launch_bounds__(256)
-like_kernel(const EmisRec *__restrict__ rec, int M, int RP, const int32_t *__restrict__ lane_pair,
+like_kernel(const EmisRec *__restrict__ rec, int M, int RP, LaneMap lane_pair,
             const double *__restrict__ params, int nlanes, double alim1, double *__restrict__ out) {
   int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= nlanes) return;
@@ -358,7 +365,7 @@ like_kernel(const EmisRec *__restrict__ rec, int M, int RP, const int32_t *__res
   LaneC C = make_lane(a, k2, k1, k0);
   double x[1][3] = {{k0, k1, k2}};
   int ex[1] = {0};
-  sweep<1, DR, NBUF>(rec, RP, lane_pair[l], 0, M, M, C, x, ex);
+  sweep<1, DR, NBUF>(rec, RP, lane_pair(l), 0, M, M, C, x, ex);
   double tot = (x[0][0] + x[0][1]) + x[0][2];
   out[l] = -(log(tot) + (double)ex[0] * kLn2);
 }
@@ -434,7 +441,7 @@ struct HalfNorm {
 
 template <bool DR, int NBUF>
 __global__ void __launch_bounds__(256)
-like_halves_kernel(const EmisRec *__restrict__ rec, int M, int RP, const int32_t *__restrict__ lane_pair,
+like_halves_kernel(const EmisRec *__restrict__ rec, int M, int RP, LaneMap lane_pair,
                    const double *__restrict__ params, int nlanes, int nlp, double alim1, double *__restrict__ part) {
   const int nb = nlp / 256;
   const bool back = (int)blockIdx.x >= nb;
@@ -444,7 +451,7 @@ like_halves_kernel(const EmisRec *__restrict__ rec, int M, int RP, const int32_t
   if (!lane_params(params, l, alim1, true, a, k2, k1, k0)) return;  // like_join_kernel rejects the lane
   LaneC C = make_lane(a, k2, k1, k0);
   const int mid = (M / 2) & ~(kGroup - 1);
-  const int lp = lane_pair[l];
+  const int lp = lane_pair(l);
   HalfNorm norm(k0, k1, k2, DR);
   if (!back) {
     double x[1][3] = {{k0, k1, k2}};
@@ -517,7 +524,7 @@ struct ChunkOut {
 
 template <bool DR>
 __global__ void __launch_bounds__(256)
-chunk_matrix_kernel(const EmisRec *__restrict__ rec, int M, int RP, const int32_t *__restrict__ lane_pair,
+chunk_matrix_kernel(const EmisRec *__restrict__ rec, int M, int RP, LaneMap lane_pair,
                     const double *__restrict__ params, int nlanes, int nlp, int nchunk, int chunk_len, double alim1,
                     int reject, ChunkOut O) {
   int bpc = nlp / 256;  // workgroups per chunk
@@ -530,7 +537,7 @@ chunk_matrix_kernel(const EmisRec *__restrict__ rec, int M, int RP, const int32_
   int sb = c * chunk_len, se = min(M, sb + chunk_len);
   double x[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
   int ex[3] = {0, 0, 0};
-  sweep<3, DR, kNbufChunk>(rec, RP, lane_pair ? lane_pair[l] : l, sb, se, M, C, x, ex);
+  sweep<3, DR, kNbufChunk>(rec, RP, lane_pair(l), sb, se, M, C, x, ex);
   size_t n = (size_t)nlp * nchunk, at = (size_t)c * nlp + l;
 #pragma unroll
   for (int i = 0; i < 3; i++) {

@@ -20,7 +20,8 @@ __global__ void lk_fix_missing_kernel(float *__restrict__ post, int R, int M, co
   if (p[0] == -1) {
     int n = 1;
     while (n < M && p[n] == -1) n++;
-    float nx = p[n < M ? n : M - 1];
+    if (n == M) return;  // the whole row is missing (a pair without a shared SNP): nothing to infer from, it stays -1
+    float nx = p[n];
     for (int j = 0; j < n; j++) p[j] = nx;
   }
   if (p[M - 1] == -1) {

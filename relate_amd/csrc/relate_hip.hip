@@ -4,6 +4,7 @@
 // result comes from the HIP kernels in kernels_*.hpp; host code only sequences launches and runs the
 // optimiser's control logic (fit.hpp / lbfgsb.hpp).
 #include "../../include/relate_hip.h"
+#include "../../include/relate_hip_bench.h"
 
 #include <hip/hip_runtime.h>
 
@@ -138,6 +139,7 @@ struct relate_hip_ctx {
   double timings[4] = {0, 0, 0, 0};
   int last_chunks[2] = {1, 1};  // SNP-axis chunks of the last like / decode launch
   long slots_like = 2048, slots_decode = 6144;  // resident waves of the chunked sweeps (set at create)
+  long single_sweep_lanes = 45056;              // launches below this many lanes are cut along the SNP axis (pick_chunks)
 };
 
 namespace {
@@ -257,7 +259,7 @@ int stage_block(relate_hip_t h, const int32_t *pairs, int P) {
 
 // SNP-axis chunking.  A sweep lane carries a serial chain of M steps; below about two waves per SIMD the
 // machine idles, so the SNP axis is cut until there are enough threads -- but a chunked step costs ~2x a plain
-// one, so a launch that already has >= ~0.7 waves per SIMD stays a single sweep (g_single_sweep_lanes).  When cutting, the number of
+// one, so a launch that already has >= ~0.7 waves per SIMD stays a single sweep (relate_hip_ctx::single_sweep_lanes).  When cutting, the number of
 // chunks is the largest one whose waves still fit `rounds` full turns of the `slots` waves the kernels of the launch
 // can hold at once (hipOccupancy at create time; for decode the least common multiple over its three kernels): one
 // chunk more would add a turn that runs nearly empty (a seventh of the run time at 6 turns).  The likelihood uses
@@ -267,12 +269,11 @@ int stage_block(relate_hip_t h, const int32_t *pairs, int P) {
 // Launches with at least this many lanes run as one sweep per lane; fewer are cut along the SNP axis.  Measured
 // crossover (M = 1e5): a lone wave per SIMD walks its chain in 10.4 ms whatever the lane count, the chunked path
 // sustains ~420 G lane-steps/s, equal at ~44 000 lanes.  RELATE_SINGLE_SWEEP_LANES overrides (tuning experiments).
-constexpr long kSingleSweepLanesDefault = 45056;
-long g_single_sweep_lanes = kSingleSweepLanesDefault;
 
-void pick_chunks(int M, long lanes, int wg_threads, long slots, int rounds, int *nchunk, int *chunk_len) {
+void pick_chunks(int M, long lanes, long single_sweep_lanes, int wg_threads, long slots, int rounds, int *nchunk,
+                 int *chunk_len) {
   long c = 1;
-  if (lanes < g_single_sweep_lanes) {
+  if (lanes < single_sweep_lanes) {
     long wg = (lanes + wg_threads - 1) / wg_threads;
     long waves_per_chunk = wg * ((wg_threads + 63) / 64);
     c = (slots * rounds) / std::max(1L, waves_per_chunk);
@@ -310,10 +311,31 @@ int ensure_chunk_buffers(relate_hip_t h, size_t n, ChunkOut *O) {
   return 0;
 }
 
-// K5 launches on lanes already uploaded to dLanePair/dParams; result in dOut (device)
-int launch_like(relate_hip_t h, int P, int nl) {
+// Where a likelihood launch finds its lanes and leaves its values, and where its chunk products / half vectors go.
+struct LikeIO {
+  LaneMap map;
+  const double *params;  // device, 3 per lane
+  double *out;           // device, 1 per lane
+  unsigned char *fixed;  // nullptr: the handle's grow-only buffers (may allocate); else a scratch of fixed_bytes
+  size_t fixed_bytes;
+};
+
+// K5 launches for nl lanes of the staged block
+int launch_like(relate_hip_t h, int nl, const LikeIO &io) {
   int nchunk, clen;
-  pick_chunks(h->M, nl, 256, h->slots_like, 12, &nchunk, &clen);
+  pick_chunks(h->M, nl, h->single_sweep_lanes, 256, h->slots_like, 12, &nchunk, &clen);
+  const int nlp = pad256(nl);
+  if (io.fixed && nchunk > 1) {  // as many chunks as the fixed scratch holds products for
+    long cmax = (long)(io.fixed_bytes / 84 / (size_t)nlp);
+    if (cmax < nchunk) {
+      if (cmax < 2) { nchunk = 1; clen = h->M; }
+      else {
+        int len = (int)((h->M + cmax - 1) / cmax);
+        clen = (len + 15) / 16 * 16;
+        nchunk = (h->M + clen - 1) / clen;
+      }
+    }
+  }
   h->last_chunks[0] = nchunk;
   const bool dr = h->o.double_recom != 0;
   if (nchunk == 1) {
@@ -322,27 +344,30 @@ int launch_like(relate_hip_t h, int P, int nl) {
     // Up to one wave per SIMD: the two-sided sweep instead (twice the lanes, half the length, like_halves_kernel).
     // RELATE_LIKE_TWO_SIDED=0 keeps the single sweep (tests, tuning).
     static const bool two_sided = [] { const char *e = getenv("RELATE_LIKE_TWO_SIDED"); return !(e && atoi(e) == 0); }();
-    if (two_sided && nl <= simd_lanes && h->M >= 64) {
-      int nlp = pad256(nl);
-      HIPCHK(h, h->dCm.ensure((size_t)12 * nlp));
+    if (two_sided && nl <= simd_lanes && h->M >= 64 && (!io.fixed || (size_t)12 * nlp * sizeof(double) <= io.fixed_bytes)) {
+      double *part = reinterpret_cast<double *>(io.fixed);
+      if (!io.fixed) {
+        HIPCHK(h, h->dCm.ensure((size_t)12 * nlp));
+        part = h->dCm.p;
+      }
       dim3 grid((unsigned)(2 * (nlp / 256)));
       if (dr)
         hipLaunchKernelGGL((like_halves_kernel<true, 4>), grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch,
-                           h->dLanePair.p, h->dParams.p, nl, nlp, h->o.alim[1], h->dCm.p);
+                           io.map, io.params, nl, nlp, h->o.alim[1], part);
       else
         hipLaunchKernelGGL((like_halves_kernel<false, 4>), grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch,
-                           h->dLanePair.p, h->dParams.p, nl, nlp, h->o.alim[1], h->dCm.p);
+                           io.map, io.params, nl, nlp, h->o.alim[1], part);
       HIPCHK(h, hipGetLastError());
-      hipLaunchKernelGGL(like_join_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, h->dCm.p, h->dParams.p, nl,
-                         nlp, h->o.alim[1], h->dOut.p);
+      hipLaunchKernelGGL(like_join_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, part, io.params, nl,
+                         nlp, h->o.alim[1], io.out);
       HIPCHK(h, hipGetLastError());
       return 0;
     }
     const int nbuf = nl <= simd_lanes ? 6 : (nl <= 2 * simd_lanes ? 4 : 2);
     dim3 grid(blocks_for(nl, 256)), block(256);
-#define LAUNCH_LIKE(DR, NB)                                                                                        \
-  hipLaunchKernelGGL((like_kernel<DR, NB>), grid, block, 0, h->stream, h->dRec.p, h->M, h->recPitch, h->dLanePair.p, \
-                     h->dParams.p, nl, h->o.alim[1], h->dOut.p)
+#define LAUNCH_LIKE(DR, NB)                                                                                   \
+  hipLaunchKernelGGL((like_kernel<DR, NB>), grid, block, 0, h->stream, h->dRec.p, h->M, h->recPitch, io.map, \
+                     io.params, nl, h->o.alim[1], io.out)
     if (dr) {
       if (nbuf == 6) LAUNCH_LIKE(true, 6);
       else if (nbuf == 4) LAUNCH_LIKE(true, 4);
@@ -356,23 +381,32 @@ int launch_like(relate_hip_t h, int P, int nl) {
     HIPCHK(h, hipGetLastError());
     return 0;
   }
-  int nlp = pad256(nl);
   size_t n = (size_t)nlp * nchunk;
   ChunkOut O;
-  int rc = ensure_chunk_buffers(h, n, &O);
-  if (rc) return rc;
+  if (io.fixed) {
+    O.m = reinterpret_cast<double *>(io.fixed);
+    O.e = reinterpret_cast<int *>(io.fixed + (size_t)72 * n);
+  } else {
+    int rc = ensure_chunk_buffers(h, n, &O);
+    if (rc) return rc;
+  }
   dim3 grid((unsigned)((size_t)(nlp / 256) * nchunk));
   if (dr)
-    hipLaunchKernelGGL(chunk_matrix_kernel<true>, grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch, h->dLanePair.p,
-                       h->dParams.p, nl, nlp, nchunk, clen, h->o.alim[1], 1, O);
+    hipLaunchKernelGGL(chunk_matrix_kernel<true>, grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch, io.map,
+                       io.params, nl, nlp, nchunk, clen, h->o.alim[1], 1, O);
   else
-    hipLaunchKernelGGL(chunk_matrix_kernel<false>, grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch, h->dLanePair.p,
-                       h->dParams.p, nl, nlp, nchunk, clen, h->o.alim[1], 1, O);
+    hipLaunchKernelGGL(chunk_matrix_kernel<false>, grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch, io.map,
+                       io.params, nl, nlp, nchunk, clen, h->o.alim[1], 1, O);
   HIPCHK(h, hipGetLastError());
-  hipLaunchKernelGGL(like_combine_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, O, h->dParams.p, nl, nlp,
-                     nchunk, h->o.alim[1], h->dOut.p);
+  hipLaunchKernelGGL(like_combine_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, O, io.params, nl, nlp,
+                     nchunk, h->o.alim[1], io.out);
   HIPCHK(h, hipGetLastError());
   return 0;
+}
+// lanes already uploaded to dLanePair/dParams; result in dOut (device)
+int launch_like(relate_hip_t h, int P, int nl) {
+  (void)P;
+  return launch_like(h, nl, LikeIO{LaneMap{h->dLanePair.p, 1}, h->dParams.p, h->dOut.p, nullptr, 0});
 }
 
 // K5 on the staged block: nl lanes, host arrays in, host array out
@@ -804,7 +838,7 @@ int copy_to_host(relate_hip_t h, void *dst, const void *src, size_t bytes) {
 int launch_decode(relate_hip_t h, int P, int f32_rows = 0) {
   const int M = h->M;
   int nchunk, clen;
-  pick_chunks(M, P, 256, h->slots_decode, 1, &nchunk, &clen);
+  pick_chunks(M, P, h->single_sweep_lanes, 256, h->slots_decode, 1, &nchunk, &clen);
   h->last_chunks[1] = nchunk;
   const bool dr = h->o.double_recom != 0;
   const int nlp = pad256(P);
@@ -821,10 +855,10 @@ int launch_decode(relate_hip_t h, int P, int f32_rows = 0) {
     HIPCHK(h, h->dBend.ensure((size_t)3 * n));
     if (dr)
       hipLaunchKernelGGL(chunk_matrix_kernel<true>, grid, dim3(256), 0, h->stream, h->dRec.p, M, h->recPitch,
-                         (const int32_t *)nullptr, h->dParams.p, P, nlp, nchunk, clen, h->o.alim[1], 0, O);
+                         LaneMap{nullptr, 1}, h->dParams.p, P, nlp, nchunk, clen, h->o.alim[1], 0, O);
     else
       hipLaunchKernelGGL(chunk_matrix_kernel<false>, grid, dim3(256), 0, h->stream, h->dRec.p, M, h->recPitch,
-                         (const int32_t *)nullptr, h->dParams.p, P, nlp, nchunk, clen, h->o.alim[1], 0, O);
+                         LaneMap{nullptr, 1}, h->dParams.p, P, nlp, nchunk, clen, h->o.alim[1], 0, O);
     HIPCHK(h, hipGetLastError());
     hipLaunchKernelGGL(decode_combine_kernel, dim3(blocks_for(P, 256)), dim3(256), 0, h->stream, O, h->dParams.p, P,
                        nlp, nchunk, h->dAstart.p, h->dBend.p);
@@ -911,12 +945,9 @@ int relate_hip_create(relate_hip_t *out, int device_id) {
                 std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
                     " (librelate_hip has no CPU fallback)");
   if (device_id < 0 || device_id >= ndev) return fail(nullptr, RELATE_E_ARG, "device_id out of range");
-  {
-    const char *e = getenv("RELATE_SINGLE_SWEEP_LANES");
-    g_single_sweep_lanes = e ? atol(e) : kSingleSweepLanesDefault;
-  }
   relate_hip_ctx *h = new relate_hip_ctx();
   h->dev = device_id;
+  if (const char *e = getenv("RELATE_SINGLE_SWEEP_LANES")) h->single_sweep_lanes = atol(e);
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
     delete h;
     return fail(nullptr, RELATE_E_HIP, "hipSetDevice/hipStreamCreate failed");

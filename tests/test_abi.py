@@ -13,8 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    with open(os.path.join(ROOT, "include", "relate_hip.h")) as fh:
-        text = fh.read()
+    text = ""
+    for f in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if f.endswith(".h"):
+            with open(os.path.join(ROOT, "include", f)) as fh:
+                text += fh.read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(relate_[a-z0-9_]+)\s*\(", text)))
 
