@@ -116,6 +116,16 @@ int relate_hip_pair_emissions(relate_hip_t h, int ind1, int ind2, int *keep, dou
 int relate_hip_like(relate_hip_t h, const int32_t *pairs /* P x 2 */, int P, const double *params, int E,
                     double *negloglik);
 
+/* relate_hip_like for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  No counterpart in the reference.  Works on the pair block the previous relate_hip_like /
+ * fit / decode call staged (P must be that block's pair count), takes DEVICE pointers (d_params P x E x 3, pair-major
+ * as relate_hip_like; d_negloglik P x E) and calls no hipMalloc / hipFree: the chunk products of a launch cut along
+ * the SNP axis and the half vectors of the two-sided sweep go to a 64 MiB array every GPU the library runs on holds
+ * until the process ends (a launch is cut into as many chunks as fit there; values agree with relate_hip_like to
+ * rounding, <= 1e-13 relative).  At most 1 048 576 lanes (P x E) per call, more is rejected.  Returns with the values in
+ * place.  Calls that overlap on one GPU (two handles, two threads) race on that array. */
+int relate_hip_like_noalloc(relate_hip_t h, int P, const double *d_params, int E, double *d_negloglik);
+
 /* run_optimization + *_optim + findmax_bfgs (src/relateHMM.cpp:1852-1971, 1597-1849; src/bfgs.c:127-199),
  * plus uLike/poLike, batched over pairs.  starts: optional P x timesToRun x 4 start records
  * {a,k2,k1,unused} replacing the rand() draws of get_rand/get_start (NULL = draw per opts.seed_mode).

@@ -104,6 +104,7 @@ def load_library():
     L.relate_hip_get_hap.argtypes = [vp, dp, dp, dp, dp, dp, ip]
     L.relate_hip_pair_emissions.argtypes = [vp, C.c_int, C.c_int, ip, dp, dp]
     L.relate_hip_like.argtypes = [vp, i32p, C.c_int, dp, C.c_int, dp]
+    L.relate_hip_like_noalloc.argtypes = [vp, C.c_int, vp, C.c_int, vp]
     L.relate_hip_fit.argtypes = [vp, i32p, C.c_int, dp, C.POINTER(RelateFit), dp]
     L.relate_hip_decode.argtypes = [vp, i32p, C.c_int, dp, dp, i8p, ip]
     L.relate_hip_decode_f32.argtypes = [vp, i32p, C.c_int, dp, C.c_int, C.POINTER(C.c_float), ip]
@@ -287,6 +288,10 @@ class Relate:
         self._chk(self.L.relate_hip_like(self.h, pp, len(p), par.ctypes.data_as(dp), par.shape[1],
                                          out.ctypes.data_as(dp)))
         return out
+
+    def like_noalloc(self, P, d_params_ptr, E, d_out_ptr):
+        """relate_hip_like_noalloc on the block staged by the previous call; device addresses in and out."""
+        self._chk(self.L.relate_hip_like_noalloc(self.h, P, C.c_void_p(d_params_ptr), E, C.c_void_p(d_out_ptr)))
 
     def fit(self, pairs, starts=None, want_conv=False):
         p, pp = self._pairs(pairs)

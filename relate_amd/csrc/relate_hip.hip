@@ -139,6 +139,7 @@ struct relate_hip_ctx {
   double timings[4] = {0, 0, 0, 0};
   int last_chunks[2] = {1, 1};  // SNP-axis chunks of the last like / decode launch
   long slots_like = 2048, slots_decode = 6144;  // resident waves of the chunked sweeps (set at create)
+  unsigned char *scratch_dev = nullptr;  // device address of `scratch` on this handle's GPU (relate_hip_like_noalloc)
   long single_sweep_lanes = 45056;              // launches below this many lanes are cut along the SNP axis (pick_chunks)
 };
 
@@ -310,6 +311,13 @@ int ensure_chunk_buffers(relate_hip_t h, size_t n, ChunkOut *O) {
   O->e = h->dCe.p;
   return 0;
 }
+
+// Scratch of relate_hip_like_noalloc: chunk products (84 B per lane and chunk) or the half vectors of the two-sided
+// sweep (96 B per lane).  One copy per GPU, held until the process ends; its device address is looked up once per
+// handle (relate_hip_create) -- in host code the array's name is not a device pointer.
+constexpr size_t kNoAllocScratchBytes = (size_t)64 << 20;
+constexpr long kNoAllocMaxLanes = 1L << 20;
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
 
 // Where a likelihood launch finds its lanes and leaves its values, and where its chunk products / half vectors go.
 struct LikeIO {
@@ -969,6 +977,14 @@ int relate_hip_create(relate_hip_t *out, int device_id) {
     // decode launches (P / 64) waves per chunk in each of its three sweeps
     h->slots_decode = lcm(lcm(sc, sf), sb);
   }
+  {
+    // the no-alloc entry point's scratch: every GPU holds its own copy of the array at its own address
+    hipError_t se = hipGetSymbolAddress((void **)&h->scratch_dev, HIP_SYMBOL(scratch));
+    if (se != hipSuccess || !h->scratch_dev) {
+      relate_hip_destroy(h);
+      return fail(nullptr, RELATE_E_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(se));
+    }
+  }
   *out = h;
   return RELATE_OK;
 }
@@ -1381,6 +1397,22 @@ int relate_hip_like(relate_hip_t h, const int32_t *pairs, int P, const double *p
     rc = like_lanes(h, pb, lp.data(), params + (size_t)b0 * E * 3, pb * E, negloglik + (size_t)b0 * E);
     if (rc) return rc;
   }
+  return RELATE_OK;
+}
+
+int relate_hip_like_noalloc(relate_hip_t h, int P, const double *d_params, int E, double *d_negloglik) {
+  int rc = require_ready(h);
+  if (rc) return rc;
+  if (!d_params || !d_negloglik || P < 1 || E < 1) return fail(h, RELATE_E_ARG, "bad arguments");
+  if ((int)h->staged.size() != 2 * P)
+    return fail(h, RELATE_E_ARG, "relate_hip_like_noalloc works on the pair block of the previous relate_hip_like / fit / decode call (" +
+                                     std::to_string(h->staged.size() / 2) + " pairs are staged, P = " + std::to_string(P) + ")");
+  if ((long)P * E > kNoAllocMaxLanes)
+    return fail(h, RELATE_E_ARG, "relate_hip_like_noalloc takes at most " + std::to_string(kNoAllocMaxLanes) +
+                                     " lanes (P x E) per call; got " + std::to_string((long)P * E));
+  rc = launch_like(h, P * E, LikeIO{LaneMap{nullptr, E}, d_params, d_negloglik, h->scratch_dev, kNoAllocScratchBytes});
+  if (rc) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return RELATE_OK;
 }
 
