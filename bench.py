@@ -30,14 +30,22 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s achievable)
 
-# Algorithmic bytes per (pair, SNP) of one launch: emission record 32 B; packed genotypes
-# 2 x 2 bit; forward checkpoint 3 doubles per 4 SNPs = 6 B; posterior 3 x 8 B.  A launch that is cut along the SNP
-# axis adds the chunk-product pass, which reads the records once more.
+# Algorithmic bytes per (pair, SNP) of one launch by this design: emission record 24 B (three
+# planes: t, S1/S0, S2/S0); packed genotypes 2 x 2 bit; tile checkpoint 84 B per 16 SNPs; posterior 3 x 8 B.  The decode is
+# two sweeps over the records: chunk products + tile checkpoints, then the backward sweep that writes the posteriors.
+CKPT = 84.0 / 16
+
+
 def algorithmic_bytes(like_chunks, decode_chunks):
-    return {"stage": 32.0 + 0.5,
-            "like": 32.0,
-            "decode_fwd": (32.0 if decode_chunks > 1 else 0.0) + 32.0 + 6.0,
-            "decode_bwd": 32.0 + 6.0 + 24.0}
+    return {"stage": 24.0 + 0.5 + 0.25,
+            "like": 24.0,
+            "decode_fwd": 24.0 + CKPT,
+            "decode_bwd": 24.0 + CKPT + 24.0}
+
+
+# SURVEY.md section 8(d)'s figures, which price the path without materialised emissions: two 2-bit genotypes per forward
+# step (K5), plus the posterior rows for the decode (K6: 0.5 + 8 x rows, rows = 3 doubles here).
+SURVEY_BYTES = {"like": 0.5, "decode": 0.5 + 8.0 * 3}
 
 
 # FP64 VALU instructions per lane-step of the likelihood kernels, counted by rocprofv3 (SQ_INSTS_VALU / wave-steps,
@@ -300,12 +308,12 @@ def main():
         gbs = {k: BYTES[k] * units / (per[k] * 1e-3) / 1e9 for k in per}
         dom = max(per, key=per.get)
         kernel_name = {"stage": "stage_pairs_win_kernel",
-                       "like": "chunk_matrix_kernel" if lc > 1 else "like_kernel",
-                       "decode_fwd": "chunk_matrix_kernel + decode_fwd_kernel" if dc > 1 else "decode_fwd_kernel",
+                       "like": "chunk_matrix_kernel<false, false>" if lc > 1 else "like_kernel",
+                       "decode_fwd": "chunk_matrix_kernel<false, true>",
                        "decode_bwd": "decode_bwd_kernel"}
         traffic = pmc_traffic(P, M, E)
-        tkey = {"stage": ["relate::stage_pairs_win_kernel"], "like": ["relate::chunk_matrix_kernel<false>"],
-                "decode_fwd": ["relate::chunk_matrix_kernel<false>", "relate::decode_fwd_kernel<false>"],
+        tkey = {"stage": ["relate::stage_pairs_win_kernel<false>"], "like": ["relate::chunk_matrix_kernel<false, false>"],
+                "decode_fwd": ["relate::chunk_matrix_kernel<false, true>"],
                 "decode_bwd": ["relate::decode_bwd_kernel<false, double>"]}[dom]
         tr = sum(traffic[k] for k in tkey) if traffic and all(k in traffic for k in tkey) else None
         like_steps_s = P * M * E / (per["like"] * 1e-3)
@@ -323,6 +331,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel_name[dom], "achieved": gbs[dom], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": gbs[dom] / HBM_PEAK_GBS, "traffic": tr,
                          "algorithmic_bytes": BYTES[dom] * units,
+                         "algorithmic_bytes_survey": SURVEY_BYTES["decode"] * units,
+                         "frac_survey_decode": SURVEY_BYTES["decode"] * units
+                                               / ((per["decode_fwd"] + per["decode_bwd"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "bytes_per_pair_snp_step": sum(BYTES.values()),
                          "note": "dominant = largest share of the step; traffic = HBM bytes per launch from the "
                                  "committed PMC passes (profiles/pmc_traffic.json), null if they were taken on another "
                                  "configuration.  The likelihood kernels are FP64-VALU-bound by design (two expm1 "

@@ -30,6 +30,7 @@ extern "C" {
 #define RELATE_E_NODEV -3   /* no usable gfx950 device */
 #define RELATE_E_NUMERIC -4 /* NaN in the recursion (the reference prints and exit(0)s, :1513-1520) */
 #define RELATE_E_NOMEM -5
+#define RELATE_E_NOSNP -6   /* relate_fit.status: the pair shares no non-missing SNP (the reference stops, :3415-3421) */
 
 #define RELATE_SYS_MAX 10000000.0 /* src/conf.h:6 -- value of an infeasible objective */
 
@@ -66,7 +67,7 @@ typedef struct {
   double uLike, poLike; /* like at (alim0,0,0) and (alim0,0,1), :3478-3481  */
   int timesRun, timesConverged;
   int nsnp;             /* SNPs kept for the pair                           */
-  int status;           /* 0 ok, RELATE_E_NUMERIC if the recursion produced NaN */
+  int status;           /* 0 ok, RELATE_E_NUMERIC if the recursion produced NaN, RELATE_E_NOSNP if nsnp == 0 (not fitted) */
 } relate_fit;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */

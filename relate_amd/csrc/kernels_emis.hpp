@@ -2,20 +2,66 @@
 // Replaces error/errorNoLD/emission2_new/errorLD/LDemission_new/LD2_new and the per-pair table
 // re-indexing remove_cross/getHighestId (src/relateHMM.cpp:2776-2975, 850-971, 481-497).  gfx950 only.
 //
-// Emission records live SNP-major in HBM: rec[s * RP + p] = {t, S_ibd0, S_ibd1, S_ibd2} (32 B) for pair p
-// of the staged block; RP >= P is the row pitch in records, chosen by the host so that consecutive SNP rows do not lie
-// a power of two apart.  A SNP dropped for that pair (a missing genotype) is {-0.0, 1, 1, 1}: an identity step
-// for the recursions, flagged by the sign bit of t; the pair's first kept SNP has t = +0.0 (the reference's
-// t[0] = 0).  Lanes of a wave hold consecutive pairs, so every step reads/writes 64 x 32 B = 2 KiB contiguous.
+// Emission records live SNP-major in HBM, 24 B per pair and SNP: t, S_ibd1 / S_ibd0, S_ibd2 / S_ibd0.  A SNP row holds
+// the pairs of the staged block in groups of 64 (one wave); a group keeps its three values as three planes of 64
+// doubles back to back (1 536 B), so every plane access of a wave is 512 contiguous bytes, the three planes of a record
+// are one immediate offset apart, and a wave's record traffic per SNP is one contiguous piece:
+//     rec[s * 3 * RP + (p / 64) * 192 + c * 64 + p % 64],   c = 0: t, 1: S1/S0, 2: S2/S0
+// (RP = pairs rounded up to a multiple of 64, chosen by the host so that consecutive SNP rows do not lie a power of
+// two apart).  Emissions matter to the recursions only up to a per-SNP factor: the factor S_ibd0 is
+// taken out here, multiplied up per pair (mantissa and power-of-two exponent, scale_reduce_kernel) and added to the
+// log-likelihood once; it cancels in posteriors.  A SNP dropped for the pair (a missing genotype) is {-0.0, 1, 1}
+// with factor 1: an identity step for the recursions, flagged by the sign bit of t; the pair's first kept SNP has
+// t = +0.0 (the reference's t[0] = 0).  The "full" format (Viterbi, inspection) has four planes t, S_ibd0, S_ibd1, S_ibd2.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace relate {
 
-struct __attribute__((aligned(32))) EmisRec {
-  double t, s0, s1, s2;
+static constexpr int kRecPlanes = 3, kRecPlanesFull = 4;
+// offset in doubles of pair column `col` inside a SNP row of `npl` planes; plane c is c * 64 further
+__host__ __device__ inline size_t rec_col_off(int col, int npl) { return (size_t)(col >> 6) * (npl * 64) + (col & 63); }
+
+// A table entry holds {S_ibd0, S_ibd1 / S_ibd0, S_ibd2 / S_ibd0} (correctly rounded divisions, once per entry), so the
+// staging kernel divides nothing.  An all-zero emission (conditioning row beyond the data) stays all zero.
+__device__ inline void store_entry(double *__restrict__ o, const double *S) {
+  bool z = S[0] == 0;
+  o[0] = S[0];
+  o[1] = z ? (S[1] == 0 ? 0.0 : INFINITY) : S[1] / S[0];
+  o[2] = z ? (S[2] == 0 ? 0.0 : INFINITY) : S[2] / S[0];
+}
+
+// running product of the factors taken out of a pair's records: mantissa and power-of-two exponent
+struct ScaleAcc {
+  double m = 1.0;
+  int e = 0;
+  __device__ inline void fold() {
+    int f = (m > 0) ? __builtin_amdgcn_frexp_exp(m) : 0;
+    m = __builtin_amdgcn_ldexp(m, -f);
+    e += f;
+  }
 };
+
+// One staged record leaves a lane: planes of row s, pair column p.  FULL: t, S0, S1, S2; else t, S1/S0, S2/S0.
+// state: 0 dropped, 1/2 kept with entry {s0, r1, r2}, 3 all-zero emission.
+template <bool FULL>
+__device__ inline void put_record(double *__restrict__ rec, int RP, int s, int p, bool live, int state, double t,
+                                  double s0, double r1, double r2, ScaleAcc &acc, int &nkept) {
+  constexpr int NPL = FULL ? kRecPlanesFull : kRecPlanes;
+  double *row = rec + (size_t)s * NPL * RP + rec_col_off(p, NPL);
+  if (state == 0) { t = -0.0; s0 = 1; r1 = 1; r2 = 1; }
+  else if (state == 3) { s0 = 0; r1 = 0; r2 = 0; }
+  nkept += state != 0;
+  acc.m *= s0;
+  if (!live) return;
+  row[0] = t;
+  if (FULL) {
+    row[64] = s0; row[128] = r1 * s0; row[192] = r2 * s0;
+  } else {
+    row[64] = r1; row[128] = r2;
+  }
+}
 
 // P(observed code o in 1..3 | true genotype index tr in 0..2): error(), src/relateHMM.cpp:2828-2855.
 // The het/hom asymmetry is the reference's and is kept literally.
@@ -153,8 +199,7 @@ __global__ void table_single_kernel(const double *__restrict__ maf, int M, doubl
   int s = tid / 9, code = tid % 9;
   double S[3];
   emis_single(1.0 - maf[s], maf[s], code / 3 + 1, code % 3 + 1, eps, S);  // maf1_local = 1 - maf2_local (:3440-3441)
-  double *o = tab1 + (size_t)tid * 3;
-  o[0] = S[0]; o[1] = S[1]; o[2] = S[2];
+  store_entry(tab1 + (size_t)tid * 3, S);
 }
 
 __global__ void table_ld_kernel(const int *__restrict__ choose, const double *__restrict__ pBA,
@@ -169,8 +214,7 @@ __global__ void table_ld_kernel(const int *__restrict__ choose, const double *__
     int o2p = code % 3, o1p = (code / 3) % 3, o2c = (code / 9) % 3, o1c = code / 27;
     emis_cond(pBA[at], pbA[at], pBa[at], pba[at], o1c + 1, o2c + 1, o1p + 1, o2p + 1, eps, S);
   }
-  double *o = tabL + (size_t)tid * 3;
-  o[0] = S[0]; o[1] = S[1]; o[2] = S[2];
+  store_entry(tabL + (size_t)tid * 3, S);
 }
 
 __device__ inline int geno_at(const uint64_t *__restrict__ G, int W, int s, int ind) {
@@ -183,13 +227,15 @@ __device__ inline int geno_at(const uint64_t *__restrict__ G, int W, int s, int 
 // pair's re-indexed LD table equals the global one, so the emission is a lookup in tabL.  Slow path: re-index
 // per the clean form of remove_cross (row r = r-th previous kept SNP, zero beyond depth back2), pick the row
 // with getHighestId's rule and evaluate the conditional emission directly.
+template <bool FULL>
 __global__ void stage_pairs_kernel(const uint64_t *__restrict__ G, int M, int W, const int32_t *__restrict__ pairs,
                                    int P, int chunk, const double *__restrict__ pos, const double *__restrict__ tab1,
                                    const double *__restrict__ tabL, const int *__restrict__ chooseG,
                                    const double *__restrict__ mea, const double *__restrict__ pBA,
                                    const double *__restrict__ pbA, const double *__restrict__ pBa,
                                    const double *__restrict__ pba, int useLD, int back, int back2, double eps,
-                                   EmisRec *__restrict__ rec, int RP) {
+                                   double *__restrict__ rec, int RP, double *__restrict__ sc_m, int *__restrict__ sc_e,
+                                   int *__restrict__ sc_n) {
   long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   int nchunk = (M + chunk - 1) / chunk;
   if (tid >= (long)P * nchunk) return;
@@ -206,28 +252,29 @@ __global__ void stage_pairs_kernel(const uint64_t *__restrict__ G, int M, int W,
     if (geno_at(G, W, s, i1) && geno_at(G, W, s, i2)) run++;
     else break;
   }
+  ScaleAcc acc;
+  int nkept = 0;
   for (int s = s0; s < s1; s++) {
     int g1 = geno_at(G, W, s, i1), g2 = geno_at(G, W, s, i2);
-    EmisRec r;
+    int state = 0;
+    double t = 0, e0 = 1, e1 = 1, e2 = 1;
     if (g1 == 0 || g2 == 0) {
-      r.t = -0.0; r.s0 = 1; r.s1 = 1; r.s2 = 1;  // identity step; sign bit = dropped
-      run = 0;
+      run = 0;  // identity step; sign bit of t = dropped
     } else {
-      if (last < 0) {
-        r.t = 0.0;  // first kept SNP: t[0] = 0 in diff (:391-404); unconditional emission (LD2_new :2955-2957)
-      } else {
+      state = 2;
+      if (last >= 0) {  // else first kept SNP: t[0] = 0 in diff (:391-404); unconditional emission (LD2_new :2955-2957)
         double d = pos[s] - pos[last];
-        r.t = d < 0 ? 10000000.0 : d;
+        t = d < 0 ? 10000000.0 : d;
       }
       if (!useLD || last < 0) {
         const double *e = tab1 + ((size_t)s * 9 + (g1 - 1) * 3 + (g2 - 1)) * 3;
-        r.s0 = e[0]; r.s1 = e[1]; r.s2 = e[2];
+        e0 = e[0]; e1 = e[1]; e2 = e[2];
       } else if (run >= min(back, s)) {
         int sc = s - 1 - chooseG[s];
         int h1 = geno_at(G, W, sc, i1), h2 = geno_at(G, W, sc, i2);
         int code = (((g1 - 1) * 3 + (g2 - 1)) * 3 + (h1 - 1)) * 3 + (h2 - 1);
         const double *e = tabL + ((size_t)s * 81 + code) * 3;
-        r.s0 = e[0]; r.s1 = e[1]; r.s2 = e[2];
+        e0 = e[0]; e1 = e[1]; e2 = e[2];
       } else {
         // slow path: rows r = 0..back-1 <-> r-th previous kept SNP at distance dd = s-1-s_prev (< back2)
         int bestS = -1, nfound = 0;  // bestS: SNP of the first row with the strictly largest measure
@@ -243,20 +290,74 @@ __global__ void stage_pairs_kernel(const uint64_t *__restrict__ G, int M, int W,
         if (nfound == 0) { bv = 0; bestS = -1; }
         if (nfound < back && 0.0 > bv) bestS = -1;  // a zero-filled row beyond the window wins (getHighestId, :492)
         if (bestS < 0) {
-          r.s0 = 0; r.s1 = 0; r.s2 = 0;  // hap frequencies of that row are zero -> S2 = 0
+          state = 3;  // hap frequencies of that row are zero -> S2 = 0
         } else {
           int dd = s - 1 - bestS;
           size_t at = (size_t)dd * M + s;
-          double S[3];
+          double S[3], E[3];
           emis_cond(pBA[at], pbA[at], pBa[at], pba[at], g1, g2, geno_at(G, W, bestS, i1), geno_at(G, W, bestS, i2),
                     eps, S);
-          r.s0 = S[0]; r.s1 = S[1]; r.s2 = S[2];
+          store_entry(E, S);
+          e0 = E[0]; e1 = E[1]; e2 = E[2];
         }
       }
       last = s;
       if (run < back) run++;
     }
-    rec[(size_t)s * RP + p] = r;
+    put_record<FULL>(rec, RP, s, p, true, state, t, e0, e1, e2, acc, nkept);
+    if ((s & 7) == 7) acc.fold();
+  }
+  acc.fold();
+  sc_m[(size_t)c * RP + p] = acc.m;
+  sc_e[(size_t)c * RP + p] = acc.e;
+  sc_n[(size_t)c * RP + p] = nkept;
+}
+
+// Folds the per-run partial products of the staging kernels in a fixed order: per pair the factor taken out of its
+// records as mantissa x 2^exponent (the likelihood kernels add its logarithm once), and the number of kept SNPs.
+// Workgroup = 64 pairs x kScaleSeg segments of the run axis; a thread folds its segment (loads unrolled: the loop is
+// latency-bound otherwise), then the first thread row folds the segments in order.
+static constexpr int kScaleSeg = 8;
+__global__ void __launch_bounds__(64 * kScaleSeg)
+scale_reduce_kernel(const double *__restrict__ sc_m, const int *__restrict__ sc_e, const int *__restrict__ sc_n,
+                    int nruns, int RP, int P, double *__restrict__ pm, int *__restrict__ pe, int *__restrict__ pn) {
+  __shared__ double lm[kScaleSeg][64];
+  __shared__ int le[kScaleSeg][64], ln[kScaleSeg][64];
+  const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + lane;
+  const int per = (nruns + kScaleSeg - 1) / kScaleSeg;
+  const int c0 = seg * per, c1 = min(nruns, c0 + per);
+  ScaleAcc acc;
+  int n = 0;
+  if (p < P) {
+    int c = c0;
+    for (; c + 8 <= c1; c += 8) {
+      double m[8];
+      int e[8], k[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        size_t at = (size_t)(c + u) * RP + p;
+        m[u] = sc_m[at]; e[u] = sc_e[at]; k[u] = sc_n[at];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) { acc.m *= m[u]; acc.e += e[u]; n += k[u]; }
+      acc.fold();  // mantissas are in [0.5, 1): eight of them stay far from underflow
+    }
+    for (; c < c1; c++) {
+      size_t at = (size_t)c * RP + p;
+      acc.m *= sc_m[at]; acc.e += sc_e[at]; n += sc_n[at];
+    }
+    acc.fold();
+  }
+  lm[seg][lane] = acc.m; le[seg][lane] = acc.e; ln[seg][lane] = n;
+  __syncthreads();
+  if (seg == 0 && p < P) {
+    ScaleAcc tot;
+    int nt = 0;
+#pragma unroll
+    for (int g = 0; g < kScaleSeg; g++) { tot.m *= lm[g][lane]; tot.e += le[g][lane]; nt += ln[g][lane]; }
+    tot.fold();
+    pm[p] = tot.m; pe[p] = tot.e; pn[p] = nt;
   }
 }
 
@@ -296,8 +397,7 @@ __global__ void table_ld_depth_kernel(const double *__restrict__ pBA, const doub
     int o2p = code % 3, o1p = (code / 3) % 3, o2c = (code / 9) % 3, o1c = code / 27;
     emis_cond(pBA[at], pbA[at], pBa[at], pba[at], o1c + 1, o2c + 1, o1p + 1, o2p + 1, eps, S);
   }
-  double *o = tabD + (size_t)tid * 3;
-  o[0] = S[0]; o[1] = S[1]; o[2] = S[2];
+  store_entry(tabD + (size_t)tid * 3, S);
 }
 
 __device__ inline uint64_t both_present(uint64_t a, uint64_t b) {  // bit 2k set iff SNP k is non-missing in both
@@ -338,32 +438,28 @@ __global__ void ld_order_kernel(const double *__restrict__ mea, int M, int back2
 // A pair with no missing genotype among its `back` nearest SNPs (99 % of lane-steps at 0.1 % missingness) takes the
 // global choose; the others walk the SNP's preference list.  The emission is then a lookup in tabD; no lane
 // evaluates the 81-term polynomial.
+template <bool FULL>
 __global__ void __launch_bounds__(256)
 stage_pairs_win_kernel(const uint64_t *__restrict__ Gt, int M, int Wt, const int32_t *__restrict__ pairs, int P,
                        int words, const double *__restrict__ pos, const double *__restrict__ tab1,
                        const double *__restrict__ tabD, const double *__restrict__ mea,
                        const int *__restrict__ chooseG, const uint8_t *__restrict__ order, int useLD, int back,
-                       int back2, EmisRec *__restrict__ rec, int RP) {
-  // Records leave through LDS: a lane's 32-byte record as two 16-byte stores at a 32-byte lane stride would touch
-  // sixteen 128-byte lines per store instruction and fill half of each; instead every wave parks its 64 records in
-  // its own 2 KiB of LDS and reads them back as 128 consecutive 16-byte pieces, so that each store instruction
-  // writes 1 KiB of whole lines.
-  __shared__ __attribute__((aligned(16))) EmisRec xch[4][64];
+                       int back2, double *__restrict__ rec, int RP, double *__restrict__ sc_m, int *__restrict__ sc_e,
+                       int *__restrict__ sc_n) {
+  // Every plane store of a wave is 64 consecutive doubles: 512 B of whole lines per instruction.
   int bpc = (P + 255) / 256;
   int c = blockIdx.x / bpc;
   int p = (blockIdx.x % bpc) * 256 + threadIdx.x;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int pw0 = p - lane;  // first pair of this wave
-  if (pw0 >= P) return;      // whole wave beyond the block
-  const int pc = p < P ? p : P - 1;  // dead lanes of a live wave shadow the last pair: they take part in the exchange
-  const bool liveA = pw0 + (lane >> 1) < P, liveB = pw0 + 32 + (lane >> 1) < P;
-  const uint64_t *r1 = Gt + (size_t)pairs[2 * pc] * Wt, *r2 = Gt + (size_t)pairs[2 * pc + 1] * Wt;
+  if (p >= P) return;
+  const uint64_t *r1 = Gt + (size_t)pairs[2 * p] * Wt, *r2 = Gt + (size_t)pairs[2 * p + 1] * Wt;
   int w0 = c * words, w1 = min(Wt, w0 + words);
   const uint64_t even = 0x5555555555555555ull;
   const uint64_t wmask = back2 >= 32 ? even : (((uint64_t)1 << (2 * back2)) - 1) & even;
   const uint64_t fastmask = (((uint64_t)1 << (2 * back)) - 1) & even;  // back <= 16
   uint64_t a_lo = 0, b_lo = 0;  // previous word of the two individuals
   int last = -1;                // last kept SNP before the current one
+  ScaleAcc acc;
+  int nkept = 0;
   if (w0 > 0) {
     a_lo = r1[w0 - 1];
     b_lo = r2[w0 - 1];
@@ -452,30 +548,19 @@ stage_pairs_win_kernel(const uint64_t *__restrict__ Gt, int M, int Wt, const int
       for (int u = 0; u < kBatch; u++) {
         int k = k0 + u;
         if (k >= kmax) continue;  // uniform
-        EmisRec r;
-        if (state[u] == 0) {
-          r.t = -0.0; r.s0 = 1; r.s1 = 1; r.s2 = 1;
-        } else {
-          double d = tpos[u] - lpos[u];
-          r.t = state[u] == 1 ? 0.0 : (d < 0 ? 10000000.0 : d);
-          bool zero = state[u] == 3;
-          r.s0 = zero ? 0.0 : v[u][0];
-          r.s1 = zero ? 0.0 : v[u][1];
-          r.s2 = zero ? 0.0 : v[u][2];
-        }
-        xch[wv][lane] = r;
-        __builtin_amdgcn_wave_barrier();
-        const double2 *q = (const double2 *)&xch[wv][0];
-        double2 pa = q[lane], pb = q[64 + lane];
-        __builtin_amdgcn_wave_barrier();
-        double2 *o = (double2 *)(rec + (size_t)(w * 32 + k) * RP + pw0);
-        if (liveA) o[lane] = pa;
-        if (liveB) o[64 + lane] = pb;
+        double d = tpos[u] - lpos[u];
+        double tt = state[u] == 1 ? 0.0 : (d < 0 ? 10000000.0 : d);
+        put_record<FULL>(rec, RP, w * 32 + k, p, true, state[u], tt, v[u][0], v[u][1], v[u][2], acc, nkept);
       }
+      if ((k0 & 4) == 4) acc.fold();  // every 8 records
     }
     a_lo = a_hi;
     b_lo = b_hi;
   }
+  acc.fold();
+  sc_m[(size_t)c * RP + p] = acc.m;
+  sc_e[(size_t)c * RP + p] = acc.e;
+  sc_n[(size_t)c * RP + p] = nkept;
 }
 
 }  // namespace relate

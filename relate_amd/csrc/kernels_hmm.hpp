@@ -17,10 +17,13 @@
 // polynomials in -a t with per-lane coefficients (LaneC); a forward step is then 13 + 14 FP64 instructions per
 // vector.  like() is reproduced to <= 1e-13 relative (tests/test_gpu_parity.py).
 //
-// Records.  rec[s * RP + p] = {t, S_ibd0, S_ibd1, S_ibd2} (32 B; RP = row pitch >= P, kernels_emis.hpp).  A SNP dropped for the pair is stored as
-// {-0.0, 1, 1, 1}: T(0) = I exactly, so the step is the identity and no lane ever branches on it; the sign bit
-// of t is the "dropped" flag for the kernels that must know (posterior = -1, Viterbi).  The pair's first kept SNP
-// has t = +0.0 (the reference's t[0] = 0): the start vector k passes through T(0) = I and picks up S.
+// Records (kernels_emis.hpp).  t, S_ibd1/S_ibd0, S_ibd2/S_ibd0 (24 B per pair and SNP) as three planes of 64 doubles per
+// group of 64 pairs and SNP row.  The recursions need emissions only up to a per-SNP factor: S_ibd0 is taken out
+// at staging time, its product per pair (mantissa sc_m, exponent sc_e) enters the log-likelihood once at the end and
+// cancels in posteriors -- a quarter of the bytes of every sweep and one multiply per vector-step less.  A SNP dropped
+// for the pair is {-0.0, 1, 1}: T(0) = I exactly, so the step is the identity and no lane ever branches on it; the
+// sign bit of t is the "dropped" flag for the kernels that must know (posterior = -1, Viterbi).  The pair's first kept
+// SNP has t = +0.0 (the reference's t[0] = 0): the start vector k passes through T(0) = I and picks up S.
 //
 // Parallelism.  One lane = one (pair, parameter point).  When a launch has too few lanes to fill 256 CUs the SNP
 // axis is cut into C chunks: the per-step matrices A_s = T(t_s) diag(S_s) compose associatively,
@@ -29,7 +32,8 @@
 // chunked step costs ~2x a plain one.  A workgroup is 256 lanes of ONE chunk, so loop bounds are scalar.
 // Between the two, a launch of up to one wave per SIMD runs two-sided (like_halves_kernel): forward half . backward half.
 //
-// Memory.  Every lane streams its column of records, 4 records (128 B) per group, double-buffered in registers.
+// Memory.  Every lane streams its column of records, 4 records (96 B) per group, double-buffered in registers; the row
+// base is wave-uniform (scalar), the lane adds its 32-bit column offset.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -39,6 +43,27 @@
 namespace relate {
 
 static constexpr int kGroup = 4;     // records per load group (two groups in flight)
+
+struct Rec {
+  double t, r1, r2;  // distance to the previous kept SNP, S_ibd1 / S_ibd0, S_ibd2 / S_ibd0
+};
+// One pair's column of the staged block: wave-uniform base (the SNP loops are uniform, so the row address is scalar)
+// plus the lane's byte offset.
+struct RecCol {
+  const double *__restrict__ base;
+  size_t row;    // row stride in doubles (3 planes x padded pairs)
+  unsigned off;  // byte offset of the pair's column inside a row
+  __device__ RecCol(const double *rec, int RP, int col)
+      : base(rec), row((size_t)kRecPlanes * RP), off(8u * (unsigned)rec_col_off(col, kRecPlanes)) {}
+  __device__ inline Rec at(int s) const {
+    const char *q = (const char *)(base + (size_t)s * row) + off;
+    Rec r;
+    r.t = *(const double *)q;
+    r.r1 = *(const double *)(q + 512);
+    r.r2 = *(const double *)(q + 1024);
+    return r;
+  }
+};
 static constexpr double kLn2 = 0.6931471805599453094;
 
 // ---- expm1 for x <= 0 ------------------------------------------------------------------------------------
@@ -185,7 +210,7 @@ __device__ inline Trans trans_at(const LaneC &C, double t) {
 //   new1 = f1 + u (f0 + f2 - f1 (r10 + r12)) = f1 - u (A + D),  A = f1 r10 - f0,  D = f1 r12 - f2
 //   new2 = f2 + u (f1 r12 - f2) - w (f2 k0 - f0 k2)
 template <int NV, bool DR, int TIER>
-__device__ inline void fwd_step(const LaneC &C, const EmisRec &r, double (&x)[NV][3]) {
+__device__ inline void fwd_step(const LaneC &C, const Rec &r, double (&x)[NV][3]) {
   if (DR) {
     double m1 = m1_at<TIER>(C, r.t);  // T_xy = (1 - e1) k_y + [x == y] e1
 #pragma unroll
@@ -193,9 +218,9 @@ __device__ inline void fwd_step(const LaneC &C, const EmisRec &r, double (&x)[NV
       double F = (x[v][0] + x[v][1]) + x[v][2];
       double g0 = __builtin_fma(-C.k0, F, x[v][0]), g1 = __builtin_fma(-C.k1, F, x[v][1]),
              g2 = __builtin_fma(-C.k2, F, x[v][2]);
-      x[v][0] = __builtin_fma(m1, g0, x[v][0]) * r.s0;
-      x[v][1] = __builtin_fma(m1, g1, x[v][1]) * r.s1;
-      x[v][2] = __builtin_fma(m1, g2, x[v][2]) * r.s2;
+      x[v][0] = __builtin_fma(m1, g0, x[v][0]);
+      x[v][1] = __builtin_fma(m1, g1, x[v][1]) * r.r1;
+      x[v][2] = __builtin_fma(m1, g2, x[v][2]) * r.r2;
     }
     return;
   }
@@ -209,16 +234,16 @@ __device__ inline void fwd_step(const LaneC &C, const EmisRec &r, double (&x)[NV
     double u0 = __builtin_fma(T.w, B, __builtin_fma(T.u, A, f0));
     double u1 = __builtin_fma(-T.u, A + D, f1);  // f0 + f2 - f1 (r10 + r12) = -(A + D): the columns of T - I sum to zero
     double u2 = __builtin_fma(-T.w, B, __builtin_fma(T.u, D, f2));
-    x[v][0] = u0 * r.s0;
-    x[v][1] = u1 * r.s1;
-    x[v][2] = u2 * r.s2;
+    x[v][0] = u0;
+    x[v][1] = u1 * r.r1;
+    x[v][2] = u2 * r.r2;
   }
 }
 
 // b <- T (S o b) (backward step through the record of the LATER SNP):  n_x = q_x + sum_{y != x} T_xy (q_y - q_x)
 template <bool DR, int TIER>
-__device__ inline void bwd_step(const LaneC &C, const EmisRec &r, double &b0, double &b1, double &b2) {
-  double q0 = r.s0 * b0, q1 = r.s1 * b1, q2 = r.s2 * b2;
+__device__ inline void bwd_step(const LaneC &C, const Rec &r, double &b0, double &b1, double &b2) {
+  double q0 = b0, q1 = r.r1 * b1, q2 = r.r2 * b2;
   if (DR) {
     double m1 = m1_at<TIER>(C, r.t);
     double G = __builtin_fma(C.k2, q2, __builtin_fma(C.k1, q1, C.k0 * q0));  // sum_y k_y q_y
@@ -259,7 +284,7 @@ struct LaneMap {
   __device__ inline int operator()(int l) const { return pair ? pair[l] : l / div; }
 };
 
-__device__ inline bool rec_dropped(const EmisRec &r) { return __builtin_signbit(r.t); }
+__device__ inline bool rec_dropped(const Rec &r) { return __builtin_signbit(r.t); }
 
 // wave-uniform tier of a group of N records: 0 if every lane has |a t| < 2^-7 for all of them, 1 if < 2^-4, else 2
 // (-1 below 2^-8 when LOW).  t is +0.0, -0.0 (dropped) or positive, so its order is the order of its high word as a
@@ -267,7 +292,7 @@ __device__ inline bool rec_dropped(const EmisRec &r) { return __builtin_signbit(
 // per group); a t whose high word equals the limit's counts as above it, which only ever picks the more careful tier.
 // NaN has the largest high word and goes to tier 2, where it propagates.
 template <int N, bool LOW = false>
-__device__ inline int group_tier(const LaneC &C, const EmisRec (&R)[N]) {
+__device__ inline int group_tier(const LaneC &C, const Rec (&R)[N]) {
   int hmax = hi_word(R[0].t);
 #pragma unroll
   for (int u = 1; u < N; u++) hmax = max(hmax, hi_word(R[u].t));
@@ -278,12 +303,12 @@ __device__ inline int group_tier(const LaneC &C, const EmisRec (&R)[N]) {
 }
 
 template <int NV, bool DR, int TIER>
-__device__ inline void fwd_group_t(const LaneC &C, const EmisRec (&R)[kGroup], double (&x)[NV][3]) {
+__device__ inline void fwd_group_t(const LaneC &C, const Rec (&R)[kGroup], double (&x)[NV][3]) {
 #pragma unroll
   for (int u = 0; u < kGroup; u++) fwd_step<NV, DR, TIER>(C, R[u], x);
 }
 template <int NV, bool DR>
-__device__ inline void fwd_group(const LaneC &C, const EmisRec (&R)[kGroup], double (&x)[NV][3]) {
+__device__ inline void fwd_group(const LaneC &C, const Rec (&R)[kGroup], double (&x)[NV][3]) {
   int tier = group_tier<kGroup, !DR>(C, R);
   if (tier < 0) fwd_group_t<NV, DR, -1>(C, R, x);
   else if (tier == 0) fwd_group_t<NV, DR, 0>(C, R, x);
@@ -291,21 +316,20 @@ __device__ inline void fwd_group(const LaneC &C, const EmisRec (&R)[kGroup], dou
   else fwd_group_t<NV, DR, 2>(C, R, x);
 }
 
-// Streams the records of rows [sb, se) of one column (row stride `stride` records) through two callbacks: groups of
-// kGroup records (the bulk) and single records (a tail of < NBUF * kGroup rows).  NBUF groups are in flight per lane
-// in a statically indexed register ring, so a wave always has (NBUF - 1) * 128 B per lane on the way from HBM while it
-// computes: with 2-3 waves per SIMD that covers the ~2 us loaded HBM latency.
+// Streams the records of rows [sb, se) of one column through two callbacks: groups of kGroup records (the bulk) and
+// single records (a tail of < NBUF * kGroup rows).  NBUF groups are in flight per lane in a statically indexed register
+// ring, so a wave always has (NBUF - 1) * 96 B per lane on the way from HBM while it computes: with 2-3 waves per SIMD
+// that covers the ~2 us loaded HBM latency.
 template <int NBUF, class FG, class FT>
-__device__ inline void stream_records(const EmisRec *__restrict__ col, size_t stride, int sb, int se, int M, FG &&on_group,
-                                      FT &&on_tail) {
+__device__ inline void stream_records(const RecCol &col, int sb, int se, int M, FG &&on_group, FT &&on_tail) {
   constexpr int span = NBUF * kGroup;
   int s = sb;
-  EmisRec buf[NBUF][kGroup];
+  Rec buf[NBUF][kGroup];
   if (s + span <= se) {
 #pragma unroll
     for (int j = 0; j < NBUF; j++)
 #pragma unroll
-      for (int u = 0; u < kGroup; u++) buf[j][u] = col[(size_t)(s + j * kGroup + u) * stride];
+      for (int u = 0; u < kGroup; u++) buf[j][u] = col.at(s + j * kGroup + u);
   }
   for (; s + span <= se; s += span) {
 #pragma unroll
@@ -314,31 +338,31 @@ __device__ inline void stream_records(const EmisRec *__restrict__ col, size_t st
       // refill with the group one ring turn ahead; clamped to the last row of the matrix so that a prefetch past the
       // end (discarded) stays a valid address
 #pragma unroll
-      for (int u = 0; u < kGroup; u++) buf[j][u] = col[(size_t)min(s + span + j * kGroup + u, M - 1) * stride];
+      for (int u = 0; u < kGroup; u++) buf[j][u] = col.at(min(s + span + j * kGroup + u, M - 1));
     }
   }
-  for (; s < se; s++) on_tail(col[(size_t)s * stride], s);
+  for (; s < se; s++) on_tail(col.at(s), s);
 }
 
-// groups in flight per lane, per kernel (register budget: 32 VGPRs per group)
-// (the chunk-product sweep: a third group measured +-1 % at 220 VGPRs, so it stays at two)
+// groups in flight per lane, per kernel (register budget: 24 VGPRs per group)
 static constexpr int kNbufChunk = 2;
-static constexpr int kNbuf = 2;  // decode sweeps; measured: 4 costs occupancy (216 vs 152 VGPRs) and gains nothing at 5 TB/s
 
 // forward recursion over rows [sb, se) for NV vectors
-template <int NV, bool DR, int NBUF>
-__device__ inline void sweep(const EmisRec *__restrict__ rec, int RP, int lp, int sb, int se, int M, const LaneC &C,
-                             double (&x)[NV][3], int (&ex)[NV]) {
+template <int NV, bool DR, int NBUF, class FC>
+__device__ inline void sweep(const RecCol &col, int sb, int se, int M, const LaneC &C, double (&x)[NV][3], int (&ex)[NV],
+                             FC &&at_tile) {
   stream_records<NBUF>(
-      rec + lp, (size_t)RP, sb, se, M,
-      [&](const EmisRec(&R)[kGroup], int s) {
+      col, sb, se, M,
+      [&](const Rec(&R)[kGroup], int s) {
+        if ((s & 12) == 0) at_tile(s >> 4);
         fwd_group<NV, DR>(C, R, x);
-        if ((s & 12) == 12) {  // every fourth group: 16 steps between renormalisations (emissions >= ~1e-8 each)
+        if ((s & 12) == 12) {  // every fourth group: 16 steps between renormalisations (emission ratios <= ~1e8 each way)
 #pragma unroll
           for (int v = 0; v < NV; v++) ex[v] += rescale3(x[v][0], x[v][1], x[v][2]);
         }
       },
-      [&](const EmisRec &r, int s) {
+      [&](const Rec &r, int s) {
+        if ((s & 15) == 0) at_tile(s >> 4);
         fwd_step<NV, DR, 2>(C, r, x);
         if ((s & 7) == 7) {  // the tail can be NBUF * kGroup - 1 records long
 #pragma unroll
@@ -349,67 +373,18 @@ __device__ inline void sweep(const EmisRec *__restrict__ rec, int RP, int lp, in
   for (int v = 0; v < NV; v++) ex[v] += rescale3(x[v][0], x[v][1], x[v][2]);
 }
 
-// K5, one sweep.  out[l] = -log-likelihood, SYS_MAX for a rejected point, NaN/inf if the recursion broke down.
-// NBUF = record groups in flight per lane, chosen by the host from the waves per SIMD the launch can fill: a lane is
-// one serial chain, so with one wave per SIMD only the depth of its own prefetch hides HBM latency (NBUF 6, 256
-// VGPRs, 100 000 steps in 10.4 ms against 13.8 ms at NBUF 2); with two waves NBUF 4 (224 VGPRs); from three waves
-// on NBUF 2 (158 VGPRs), where a deeper ring would cost the third wave.
-template <bool DR, int NBUF>
-__global__ void __launch_bounds__(256)
-like_kernel(const EmisRec *__restrict__ rec, int M, int RP, LaneMap lane_pair,
-            const double *__restrict__ params, int nlanes, double alim1, double *__restrict__ out) {
-  int l = blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= nlanes) return;
-  double a, k2, k1, k0;
-  if (!lane_params(params, l, alim1, true, a, k2, k1, k0)) { out[l] = 10000000.0; return; }
-  LaneC C = make_lane(a, k2, k1, k0);
-  double x[1][3] = {{k0, k1, k2}};
-  int ex[1] = {0};
-  sweep<1, DR, NBUF>(rec, RP, lane_pair(l), 0, M, M, C, x, ex);
-  double tot = (x[0][0] + x[0][1]) + x[0][2];
-  out[l] = -(log(tot) + (double)ex[0] * kLn2);
+// The factor taken out of a pair's records at staging time (kernels_emis.hpp): mantissa and exponent per pair.
+struct PairScale {
+  const double *__restrict__ m;
+  const int *__restrict__ e;
+};
+// -log-likelihood from the final vector sum `tot` with exponent `ex` and the pair's factor
+__device__ inline double neg_loglik(double tot, long ex, const PairScale &S, int pair) {
+  return -(log(tot * S.m[pair]) + (double)(ex + S.e[pair]) * kLn2);
 }
 
-// The same records from the last row down (the backward half of the two-sided likelihood): groups of kGroup rows
-// [base, base + kGroup) are handed over in descending order of base, then single rows down to sb.
-template <int NBUF, class FG, class FT>
-__device__ inline void stream_records_rev(const EmisRec *__restrict__ col, size_t stride, int sb, int se, FG &&on_group,
-                                          FT &&on_tail) {
-  constexpr int span = NBUF * kGroup;
-  int s = se;  // rows [sb, s) are still to do
-  EmisRec buf[NBUF][kGroup];
-  if (s - span >= sb) {
-#pragma unroll
-    for (int j = 0; j < NBUF; j++)
-#pragma unroll
-      for (int u = 0; u < kGroup; u++) buf[j][u] = col[(size_t)(s - (j + 1) * kGroup + u) * stride];
-  }
-  for (; s - span >= sb; s -= span) {
-#pragma unroll
-    for (int j = 0; j < NBUF; j++) {
-      on_group(buf[j], s - (j + 1) * kGroup);
-      // refill one ring turn further down; clamped to row 0 so that a prefetch below the range (discarded) stays valid
-#pragma unroll
-      for (int u = 0; u < kGroup; u++) buf[j][u] = col[(size_t)max(s - span - (j + 1) * kGroup + u, 0) * stride];
-    }
-  }
-  for (s = s - 1; s >= sb; s--) on_tail(col[(size_t)s * stride], s);
-}
-
-template <bool DR, int TIER>
-__device__ inline void bwd_group_t(const LaneC &C, const EmisRec (&R)[kGroup], double &b0, double &b1, double &b2) {
-#pragma unroll
-  for (int u = kGroup - 1; u >= 0; u--) bwd_step<DR, TIER>(C, R[u], b0, b1, b2);
-}
-
-// K5, two-sided.  The likelihood is alpha_mid . beta_mid for any cut: workgroups [0, nb) sweep rows [0, mid) forward
-// from the start vector k, workgroups [nb, 2 nb) sweep rows [mid, M) backward from the vector of ones, and
-// like_join_kernel takes the dot product.  Twice the lanes at half the length for the same arithmetic: a launch of
-// up to one wave per SIMD (a serial chain per lane, 62 % of the issue rate) becomes one of up to two.
-// part: 12 x nlp doubles (alpha[3], its three exponents, beta[3], its three exponents), nlp = lanes padded to 256.
-//
-// What the single sweep gets for free and this one must look after: a component that does not reach the likelihood
-// may outgrow, over 10^5 SNPs, the ones that do by more than the exponent range.
+// Exponents of a likelihood vector.  What a single common exponent would lose: a component that does not reach the
+// likelihood may outgrow, over 10^5 SNPs, the ones that do by more than the exponent range.
 //  * A state with k_x == 0 is never entered (T_yx = 0 for every y) and never held (alpha_x == 0): its beta is cleared
 //    at the start and at every rescaling (k = (0, 1, 0), the poLike lane, gave beta_1 = 0 without).
 //  * k1 == 0 makes T the identity (not under double recombination): states 0 and 2 are two separate chains, alpha_0 may win the first half and beta_2
@@ -439,9 +414,105 @@ struct HalfNorm {
   }
 };
 
+// sum_c pr[c] 2^{ex[c]} as (value in [0.5, 1), exponent); NaN from a broken recursion propagates
+__device__ inline double combine3(const double (&pr)[3], const int (&ex)[3], long &eout) {
+  int emax = -2147483647;
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+    if (pr[c] > 0 && ex[c] > emax) emax = ex[c];
+  double tot = 0;
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+    if (pr[c] > 0) tot += ldexp(pr[c], max(ex[c] - emax, -2200));
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+    if (!(pr[c] >= 0)) tot = pr[c];
+  int fe = tot > 0 ? __builtin_amdgcn_frexp_exp(tot) : 0;
+  eout = (long)emax + fe;
+  return __builtin_amdgcn_ldexp(tot, -fe);
+}
+
+// forward half of a likelihood sweep: rows [sb, se) from x, exponents in norm
+template <bool DR, int NBUF>
+__device__ inline void like_forward(const RecCol &col, int sb, int se, int M, const LaneC &C, double (&x)[1][3],
+                                    HalfNorm &norm) {
+  stream_records<NBUF>(
+      col, sb, se, M,
+      [&](const Rec(&R)[kGroup], int s) {
+        fwd_group<1, DR>(C, R, x);
+        if ((s & 12) == 12) norm(x[0][0], x[0][1], x[0][2]);  // every fourth group: 16 steps between renormalisations
+      },
+      [&](const Rec &r, int s) {
+        fwd_step<1, DR, 2>(C, r, x);
+        if ((s & 7) == 7) norm(x[0][0], x[0][1], x[0][2]);  // the tail can be NBUF * kGroup - 1 records long
+      });
+  norm(x[0][0], x[0][1], x[0][2]);
+}
+
+// K5, one sweep.  out[l] = -log-likelihood, SYS_MAX for a rejected point, NaN/inf if the recursion broke down.
+// NBUF = record groups in flight per lane, chosen by the host from the waves per SIMD the launch can fill: a lane is
+// one serial chain, so with one wave per SIMD only the depth of its own prefetch hides HBM latency; with two waves
+// NBUF 4; from three waves on NBUF 2, where a deeper ring would cost the third wave.
 template <bool DR, int NBUF>
 __global__ void __launch_bounds__(256)
-like_halves_kernel(const EmisRec *__restrict__ rec, int M, int RP, LaneMap lane_pair,
+like_kernel(const double *__restrict__ rec, int M, int RP, LaneMap lane_pair, PairScale scale,
+            const double *__restrict__ params, int nlanes, double alim1, double *__restrict__ out) {
+  int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= nlanes) return;
+  double a, k2, k1, k0;
+  if (!lane_params(params, l, alim1, true, a, k2, k1, k0)) { out[l] = 10000000.0; return; }
+  LaneC C = make_lane(a, k2, k1, k0);
+  double x[1][3] = {{k0, k1, k2}};
+  HalfNorm norm(k0, k1, k2, DR);
+  const int lp = lane_pair(l);
+  like_forward<DR, NBUF>(RecCol(rec, RP, lp), 0, M, M, C, x, norm);
+  const double pr[3] = {x[0][0], x[0][1], x[0][2]};
+  const int ex[3] = {norm.e0, norm.e1, norm.e2};
+  long e;
+  double tot = combine3(pr, ex, e);
+  out[l] = neg_loglik(tot, e, scale, lp);
+}
+
+// The same records from the last row down (the backward half of the two-sided likelihood): groups of kGroup rows
+// [base, base + kGroup) are handed over in descending order of base, then single rows down to sb.
+template <int NBUF, class FG, class FT>
+__device__ inline void stream_records_rev(const RecCol &col, int sb, int se, FG &&on_group, FT &&on_tail) {
+  constexpr int span = NBUF * kGroup;
+  int s = se;  // rows [sb, s) are still to do
+  Rec buf[NBUF][kGroup];
+  if (s - span >= sb) {
+#pragma unroll
+    for (int j = 0; j < NBUF; j++)
+#pragma unroll
+      for (int u = 0; u < kGroup; u++) buf[j][u] = col.at(s - (j + 1) * kGroup + u);
+  }
+  for (; s - span >= sb; s -= span) {
+#pragma unroll
+    for (int j = 0; j < NBUF; j++) {
+      on_group(buf[j], s - (j + 1) * kGroup);
+      // refill one ring turn further down; clamped to row 0 so that a prefetch below the range (discarded) stays valid
+#pragma unroll
+      for (int u = 0; u < kGroup; u++) buf[j][u] = col.at(max(s - span - (j + 1) * kGroup + u, 0));
+    }
+  }
+  for (s = s - 1; s >= sb; s--) on_tail(col.at(s), s);
+}
+
+template <bool DR, int TIER>
+__device__ inline void bwd_group_t(const LaneC &C, const Rec (&R)[kGroup], double &b0, double &b1, double &b2) {
+#pragma unroll
+  for (int u = kGroup - 1; u >= 0; u--) bwd_step<DR, TIER>(C, R[u], b0, b1, b2);
+}
+
+// K5, two-sided.  The likelihood is alpha_mid . beta_mid for any cut: workgroups [0, nb) sweep rows [0, mid) forward
+// from the start vector k, workgroups [nb, 2 nb) sweep rows [mid, M) backward from the vector of ones, and
+// like_join_kernel takes the dot product.  Twice the lanes at half the length for the same arithmetic: a launch of
+// up to one wave per SIMD (a serial chain per lane, 62 % of the issue rate) becomes one of up to two.
+// part: 12 x nlp doubles (alpha[3], its three exponents, beta[3], its three exponents), nlp = lanes padded to 256.
+//
+template <bool DR, int NBUF>
+__global__ void __launch_bounds__(256)
+like_halves_kernel(const double *__restrict__ rec, int M, int RP, LaneMap lane_pair,
                    const double *__restrict__ params, int nlanes, int nlp, double alim1, double *__restrict__ part) {
   const int nb = nlp / 256;
   const bool back = (int)blockIdx.x >= nb;
@@ -451,28 +522,18 @@ like_halves_kernel(const EmisRec *__restrict__ rec, int M, int RP, LaneMap lane_
   if (!lane_params(params, l, alim1, true, a, k2, k1, k0)) return;  // like_join_kernel rejects the lane
   LaneC C = make_lane(a, k2, k1, k0);
   const int mid = (M / 2) & ~(kGroup - 1);
-  const int lp = lane_pair(l);
+  const RecCol col(rec, RP, lane_pair(l));
   HalfNorm norm(k0, k1, k2, DR);
   if (!back) {
     double x[1][3] = {{k0, k1, k2}};
-    stream_records<NBUF>(
-        rec + lp, (size_t)RP, 0, mid, M,
-        [&](const EmisRec(&R)[kGroup], int s) {
-          fwd_group<1, DR>(C, R, x);
-          if ((s & 12) == 12) norm(x[0][0], x[0][1], x[0][2]);  // every fourth group, as sweep()
-        },
-        [&](const EmisRec &r, int s) {
-          fwd_step<1, DR, 2>(C, r, x);
-          if ((s & 7) == 7) norm(x[0][0], x[0][1], x[0][2]);
-        });
-    norm(x[0][0], x[0][1], x[0][2]);
+    like_forward<DR, NBUF>(col, 0, mid, M, C, x, norm);
     norm.store(part + l, (size_t)nlp, x[0][0], x[0][1], x[0][2]);
     return;
   }
   double b0 = 1, b1 = 1, b2 = 1;
   stream_records_rev<NBUF>(
-      rec + lp, (size_t)RP, mid, M,
-      [&](const EmisRec(&R)[kGroup], int s) {
+      col, mid, M,
+      [&](const Rec(&R)[kGroup], int s) {
         int tier = group_tier<kGroup, !DR>(C, R);
         if (tier < 0) bwd_group_t<DR, -1>(C, R, b0, b1, b2);
         else if (tier == 0) bwd_group_t<DR, 0>(C, R, b0, b1, b2);
@@ -480,7 +541,7 @@ like_halves_kernel(const EmisRec *__restrict__ rec, int M, int RP, LaneMap lane_
         else bwd_group_t<DR, 2>(C, R, b0, b1, b2);
         if ((s & 12) == 0) norm(b0, b1, b2);
       },
-      [&](const EmisRec &r, int s) {
+      [&](const Rec &r, int s) {
         bwd_step<DR, 2>(C, r, b0, b1, b2);
         if ((s & 7) == 0) norm(b0, b1, b2);
       });
@@ -489,28 +550,22 @@ like_halves_kernel(const EmisRec *__restrict__ rec, int M, int RP, LaneMap lane_
 }
 
 __global__ void __launch_bounds__(256)
-like_join_kernel(const double *__restrict__ part, const double *__restrict__ params, int nlanes, int nlp, double alim1,
-                 double *__restrict__ out) {
+like_join_kernel(const double *__restrict__ part, LaneMap lane_pair, PairScale scale, const double *__restrict__ params,
+                 int nlanes, int nlp, double alim1, double *__restrict__ out) {
   int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= nlanes) return;
   double a, k2, k1, k0;
   if (!lane_params(params, l, alim1, true, a, k2, k1, k0)) { out[l] = 10000000.0; return; }
   double pr[3];
-  int ex[3], emax = -2147483647;
+  int ex[3];
 #pragma unroll
   for (int c = 0; c < 3; c++) {
     pr[c] = part[(size_t)c * nlp + l] * part[(size_t)(6 + c) * nlp + l];
     ex[c] = (int)part[(size_t)(3 + c) * nlp + l] + (int)part[(size_t)(9 + c) * nlp + l];
-    if (pr[c] > 0 && ex[c] > emax) emax = ex[c];
   }
-  double tot = 0;
-#pragma unroll
-  for (int c = 0; c < 3; c++)
-    if (pr[c] > 0) tot += ldexp(pr[c], max(ex[c] - emax, -2000));
-#pragma unroll
-  for (int c = 0; c < 3; c++)
-    if (!(pr[c] >= 0)) tot = pr[c];  // NaN from a broken recursion propagates, as in the single sweep
-  out[l] = -(log(tot) + (double)emax * kLn2);
+  long e;
+  double tot = combine3(pr, ex, e);
+  out[l] = neg_loglik(tot, e, scale, lane_pair(l));
 }
 
 // Chunk products.  Thread (chunk c, lane l) at index at = c * nlp + l (nlp = lanes padded to 256): rows X[i][.]
@@ -521,12 +576,28 @@ struct ChunkOut {
   double *m;  // 9 x n
   int *e;     // 3 x n
 };
+// Tile checkpoints of the decode (CKPT): the partial product of the chunk up to the start of every tile of kTile = 16
+// SNPs, same row/exponent form.  Per tile and group of 64 pairs: nine planes of 64 doubles, then three of 64 ints
+// (5 376 B back to back).  The backward pass turns one into the forward vector entering the tile
+// (alpha_chunk_start . X) and recomputes the 16 vectors inside: 84 B per 16 SNPs in place of a forward pass of its own
+// over the records.
+static constexpr size_t kCkptGroupBytes = 9 * 512 + 3 * 256;
+struct TileCkpt {
+  unsigned char *base;
+  size_t tile_stride;  // bytes: groups of 64 pairs x kCkptGroupBytes
+  __device__ inline double *m(int tile, int p) const {
+    return (double *)(base + (size_t)tile * tile_stride + (size_t)(p >> 6) * kCkptGroupBytes) + (p & 63);
+  }
+  __device__ inline int *e(int tile, int p) const {
+    return (int *)(base + (size_t)tile * tile_stride + (size_t)(p >> 6) * kCkptGroupBytes + 9 * 512) + (p & 63);
+  }
+};
 
-template <bool DR>
+template <bool DR, bool CKPT>
 __global__ void __launch_bounds__(256)
-chunk_matrix_kernel(const EmisRec *__restrict__ rec, int M, int RP, LaneMap lane_pair,
+chunk_matrix_kernel(const double *__restrict__ rec, int M, int RP, LaneMap lane_pair,
                     const double *__restrict__ params, int nlanes, int nlp, int nchunk, int chunk_len, double alim1,
-                    int reject, ChunkOut O) {
+                    int reject, ChunkOut O, TileCkpt ck, int col0) {  // col0: first column of the block's pairs (CKPT)
   int bpc = nlp / 256;  // workgroups per chunk
   int c = blockIdx.x / bpc;
   int l = (blockIdx.x % bpc) * 256 + threadIdx.x;
@@ -537,7 +608,19 @@ chunk_matrix_kernel(const EmisRec *__restrict__ rec, int M, int RP, LaneMap lane
   int sb = c * chunk_len, se = min(M, sb + chunk_len);
   double x[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
   int ex[3] = {0, 0, 0};
-  sweep<3, DR, kNbufChunk>(rec, RP, lane_pair(l), sb, se, M, C, x, ex);
+  const int lp = lane_pair(l);
+  sweep<3, DR, kNbufChunk>(RecCol(rec, RP, col0 + lp), sb, se, M, C, x, ex, [&](int tile) {
+    if (CKPT) {
+      double *qm = ck.m(tile, lp);
+      int *qe = ck.e(tile, lp);
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int y = 0; y < 3; y++) qm[(i * 3 + y) * 64] = x[i][y];
+        qe[i * 64] = ex[i];
+      }
+    }
+  });
   size_t n = (size_t)nlp * nchunk, at = (size_t)c * nlp + l;
 #pragma unroll
   for (int i = 0; i < 3; i++) {
@@ -562,19 +645,23 @@ __device__ inline ChunkProd load_chunk(const ChunkOut &O, size_t n, size_t at) {
   return X;
 }
 
-// alpha <- alpha * (chunk product); returns the exponent moved out
+// alpha <- alpha * (chunk product); returns the exponent moved out.  The common exponent is that of the largest
+// term a_i 2^{e_i}, so a component is lost only when it is 2^-1074 below the leading one (with k1 = 0 the states are
+// separate chains whose products drift thousands of binades apart and back).
 __device__ inline int apply_chunk_fwd(double &f0, double &f1, double &f2, const ChunkProd &X) {
   double a[3] = {f0, f1, f2};
-  int emax = -2147483647;
+  int et[3], emax = -2147483647;
 #pragma unroll
-  for (int i = 0; i < 3; i++)
-    if (a[i] > 0 && X.e[i] > emax) emax = X.e[i];
+  for (int i = 0; i < 3; i++) {
+    et[i] = a[i] > 0 ? __builtin_amdgcn_frexp_exp(a[i]) + X.e[i] : -2147483647;
+    emax = max(emax, et[i]);
+  }
   if (emax == -2147483647) { f0 = f1 = f2 = 0; return 0; }
   double r0 = 0, r1 = 0, r2 = 0;
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     if (!(a[i] > 0)) continue;
-    double w = ldexp(a[i], X.e[i] - emax);
+    double w = ldexp(a[i], max(X.e[i] - emax, -2200));
     r0 += w * X.m[i * 3 + 0];
     r1 += w * X.m[i * 3 + 1];
     r2 += w * X.m[i * 3 + 2];
@@ -583,10 +670,12 @@ __device__ inline int apply_chunk_fwd(double &f0, double &f1, double &f2, const 
   return emax;
 }
 
-// K5 combine: folds the C chunk products of every lane into -log-likelihood.
+// K5 combine: folds the C chunk products of every lane into -log-likelihood.  A lane with k1 = 0 (T = I, not under
+// double recombination) carries its states as separate chains, each on its own exponent (HalfNorm): the products are
+// diagonal and the chains may drift further apart than a common exponent holds.
 __global__ void __launch_bounds__(256)
-like_combine_kernel(ChunkOut O, const double *__restrict__ params, int nlanes, int nlp, int nchunk, double alim1,
-                    double *__restrict__ out) {
+like_combine_kernel(ChunkOut O, LaneMap lane_pair, PairScale scale, const double *__restrict__ params, int nlanes,
+                    int nlp, int nchunk, double alim1, int double_recom, double *__restrict__ out) {
   int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= nlanes) return;
   double a, k2, k1, k0;
@@ -594,21 +683,38 @@ like_combine_kernel(ChunkOut O, const double *__restrict__ params, int nlanes, i
   size_t n = (size_t)nlp * nchunk;
   double f0 = k0, f1 = k1, f2 = k2;
   long esum = 0;
+  double tot;
   ChunkProd X = load_chunk(O, n, (size_t)l);
-  for (int c = 0; c < nchunk; c++) {
-    ChunkProd Xn = load_chunk(O, n, (size_t)min(c + 1, nchunk - 1) * nlp + l);
-    esum += apply_chunk_fwd(f0, f1, f2, X);
-    esum += rescale3(f0, f1, f2);
-    X = Xn;
+  if (!double_recom && k1 == 0) {
+    int e0 = 0, e2 = 0;
+    for (int c = 0; c < nchunk; c++) {
+      ChunkProd Xn = load_chunk(O, n, (size_t)min(c + 1, nchunk - 1) * nlp + l);
+      f0 *= X.m[0]; f2 *= X.m[8];
+      int g0 = f0 > 0 ? __builtin_amdgcn_frexp_exp(f0) : 0, g2 = f2 > 0 ? __builtin_amdgcn_frexp_exp(f2) : 0;
+      f0 = __builtin_amdgcn_ldexp(f0, -g0); f2 = __builtin_amdgcn_ldexp(f2, -g2);
+      e0 += X.e[0] + g0; e2 += X.e[2] + g2;
+      X = Xn;
+    }
+    const double pr[3] = {f0, 0.0, f2};
+    const int ex[3] = {e0, 0, e2};
+    tot = combine3(pr, ex, esum);
+  } else {
+    for (int c = 0; c < nchunk; c++) {
+      ChunkProd Xn = load_chunk(O, n, (size_t)min(c + 1, nchunk - 1) * nlp + l);
+      esum += apply_chunk_fwd(f0, f1, f2, X);
+      esum += rescale3(f0, f1, f2);
+      X = Xn;
+    }
+    tot = (f0 + f1) + f2;
   }
-  double tot = (f0 + f1) + f2;
-  out[l] = -(log(tot) + (double)esum * kLn2);
+  out[l] = neg_loglik(tot, esum, scale, lane_pair(l));
 }
 
 // ---- K6 ----------------------------------------------------------------------------------------------------
-// Forward checkpoints (one vector per group of kGroup = 4 SNPs) go to three planes; the boundary vectors of the chunked sweep:
-// astart[(c * nlp + p) * 3 ..] = forward vector entering chunk c, bend[...] = backward vector at the last SNP of
-// chunk c.  Any positive scale factor cancels in the posterior, so vectors are normalised with v_rcp_f64.
+// Pass A (chunk_matrix_kernel<DR, true>) leaves every chunk's product and the tile checkpoints; decode_combine_kernel
+// folds the products into the boundary vectors: astart[(c * nlp + p) * 3 ..] = forward vector entering chunk c,
+// bend[...] = backward vector at the last SNP of chunk c; pass B (decode_bwd_kernel) walks every chunk backwards.  Any
+// positive scale factor cancels in the posterior, so vectors are normalised with v_rcp_f64.
 __device__ inline void norm_fast(double &x0, double &x1, double &x2) {
   double s = (x0 + x1) + x2;
   double inv = (s > 0) ? __builtin_amdgcn_rcp(s) : 1.0;
@@ -645,12 +751,12 @@ decode_combine_kernel(ChunkOut O, const double *__restrict__ params, int P, int 
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       v[i] = X.m[i * 3 + 0] * b0 + X.m[i * 3 + 1] * b1 + X.m[i * 3 + 2] * b2;
-      if (v[i] > 0 && X.e[i] > emax) emax = X.e[i];
+      if (v[i] > 0) emax = max(emax, __builtin_amdgcn_frexp_exp(v[i]) + X.e[i]);
     }
     if (emax != -2147483647) {
-      b0 = v[0] > 0 ? ldexp(v[0], X.e[0] - emax) : 0;
-      b1 = v[1] > 0 ? ldexp(v[1], X.e[1] - emax) : 0;
-      b2 = v[2] > 0 ? ldexp(v[2], X.e[2] - emax) : 0;
+      b0 = v[0] > 0 ? ldexp(v[0], max(X.e[0] - emax, -2200)) : 0;
+      b1 = v[1] > 0 ? ldexp(v[1], max(X.e[1] - emax, -2200)) : 0;
+      b2 = v[2] > 0 ? ldexp(v[2], max(X.e[2] - emax, -2200)) : 0;
       norm_fast(b0, b1, b2);
     }
     X = Xn;
@@ -658,115 +764,75 @@ decode_combine_kernel(ChunkOut O, const double *__restrict__ params, int P, int 
 }
 
 // Posterior tiles.  The backward pass works on tiles of kTile = 16 SNPs (chunk starts are multiples of 16) made of
-// four groups of kGroup = 4: the forward pass stores only the normalised vector ENTERING every half tile (3
-// doubles per 4 SNPs); the backward pass recomputes the 4 forward vectors of a half tile from that checkpoint
-// while it holds the records anyway.  Recomputing costs ~35 FP64 instructions per step in an HBM-bound kernel and
-// removes 36 of the 136 bytes per (pair, SNP) that a stored forward matrix costs.
+// four groups of kGroup = 4.  From the tile's checkpoint it forms the forward vector entering the tile, walks the tile
+// forward once keeping the vector entering each group, then takes the groups last to first: four forward vectors
+// recomputed from the group's entry vector, four backward steps, four posteriors.  Recomputing costs ~1.75 forward
+// steps per SNP in an HBM-bound kernel; a stored forward matrix would cost 24 B per (pair, SNP) written and read.
 static constexpr int kTile = 16;
 static constexpr int kTilePad = kTile + 1;
-static constexpr int kBwdThreads = 64;  // one wave per workgroup: 13.5 KiB of LDS each, up to 11 per CU
+static constexpr int kBwdThreads = 64;  // one wave per workgroup: 13.5 KiB of LDS each
 
 template <bool DR, int TIER>
-__device__ inline void dec_fwd_group(const LaneC &C, const EmisRec (&A)[kGroup], double (&x)[1][3], int &m) {
+__device__ inline void dec_tile(const LaneC &C, const Rec (&R)[kTile], double f0, double f1, double f2, int tb, int te,
+                                double &b0, double &b1, double &b2, double (&tile)[3][kBwdThreads][kTilePad]) {
+  constexpr int NG = kTile / kGroup;
+  double G[NG][3];
+  {
+    double x[1][3] = {{f0, f1, f2}};
 #pragma unroll
-  for (int u = 0; u < kGroup; u++) {
-    fwd_step<1, DR, TIER>(C, A[u], x);
-    m += rec_dropped(A[u]) ? 0 : 1;
+    for (int g = 0; g < NG; g++) {
+      G[g][0] = x[0][0]; G[g][1] = x[0][1]; G[g][2] = x[0][2];
+      if (g == NG - 1) break;
+#pragma unroll
+      for (int u = 0; u < kGroup; u++) fwd_step<1, DR, TIER>(C, R[g * kGroup + u], x);
+    }
   }
-}
-template <bool DR>
-__device__ inline void dec_fwd_dispatch(const LaneC &C, const EmisRec (&A)[kGroup], double (&x)[1][3], int &m) {
-  int tier = group_tier<kGroup>(C, A);
-  if (tier == 0) dec_fwd_group<DR, 0>(C, A, x, m);
-  else if (tier == 1) dec_fwd_group<DR, 1>(C, A, x, m);
-  else dec_fwd_group<DR, 2>(C, A, x, m);
-}
-__device__ inline void put_ckpt(double *__restrict__ q, size_t plane, double (&x)[1][3]) {
-  norm_fast(x[0][0], x[0][1], x[0][2]);
-  q[0] = x[0][0]; q[plane] = x[0][1]; q[2 * plane] = x[0][2];
-}
-
-// forward sweep inside one chunk; workgroup = 256 pairs of one chunk; astart == nullptr means nchunk == 1.
-// ckpt[(r * nhalf + s / 4) * P + p]: vector entering the half tile that starts at SNP s.
-template <bool DR>
-__global__ void __launch_bounds__(256)
-decode_fwd_kernel(const EmisRec *__restrict__ rec, int M, int P, int RP, const double *__restrict__ params, int nlp,
-                  int chunk_len, const double *__restrict__ astart, double *__restrict__ ckpt, int *__restrict__ nsnp) {
-  int bpc = nlp / 256;
-  int c = blockIdx.x / bpc;
-  int p = (blockIdx.x % bpc) * 256 + threadIdx.x;
-  if (p >= P) return;
-  double a = params[3 * p], k2 = params[3 * p + 1], k1 = params[3 * p + 2];
-  double k0 = 1 - k2 - k1;
-  LaneC C = make_lane(a, k2, k1, k0);
-  int sb = c * chunk_len, se = min(M, sb + chunk_len);
-  double x[1][3] = {{k0, k1, k2}};
-  if (astart) {
-    size_t at = ((size_t)c * nlp + p) * 3;
-    x[0][0] = astart[at]; x[0][1] = astart[at + 1]; x[0][2] = astart[at + 2];
+#pragma unroll
+  for (int g = NG - 1; g >= 0; g--) {
+    const int hb = tb + g * kGroup;
+    if (hb >= te) continue;  // uniform: ragged last tile
+    double F[kGroup][3];
+    {
+      double x[1][3] = {{G[g][0], G[g][1], G[g][2]}};
+#pragma unroll
+      for (int u = 0; u < kGroup; u++) {
+        fwd_step<1, DR, TIER>(C, R[g * kGroup + u], x);
+        F[u][0] = x[0][0]; F[u][1] = x[0][1]; F[u][2] = x[0][2];
+      }
+    }
+#pragma unroll
+    for (int u = kGroup - 1; u >= 0; u--) {
+      if (hb + u >= te) continue;  // uniform
+      const Rec &r = R[g * kGroup + u];
+      double p0 = F[u][0] * b0, p1 = F[u][1] * b1, p2 = F[u][2] * b2;
+      double sum = (p0 + p1) + p2;
+      double inv = __builtin_amdgcn_rcp(sum);
+      inv = inv * __builtin_fma(-sum, inv, 2.0);
+      inv = inv * __builtin_fma(-sum, inv, 2.0);
+      bool dr = rec_dropped(r);
+      const int e = g * kGroup + u;
+      tile[2][threadIdx.x][e] = dr ? -1.0 : p0 * inv;  // row2 = IBD0
+      tile[1][threadIdx.x][e] = dr ? -1.0 : p1 * inv;
+      tile[0][threadIdx.x][e] = dr ? -1.0 : p2 * inv;  // row0 = IBD2
+      bwd_step<DR, TIER>(C, r, b0, b1, b2);
+      norm_fast(b0, b1, b2);
+    }
   }
-  const size_t stride = (size_t)RP;  // checkpoint rows share the record pitch (no power-of-two row distance)
-  const size_t plane = (size_t)((M + kGroup - 1) / kGroup) * RP;
-  double *kcol = ckpt + p;
-  int m = 0;
-  stream_records<kNbuf>(
-      rec + p, (size_t)RP, sb, se, M,
-      [&](const EmisRec(&R)[kGroup], int s) {
-        put_ckpt(kcol + (size_t)(s / kGroup) * stride, plane, x);
-        dec_fwd_dispatch<DR>(C, R, x, m);
-      },
-      [&](const EmisRec &r, int s) {
-        if ((s & (kGroup - 1)) == 0) put_ckpt(kcol + (size_t)(s / kGroup) * stride, plane, x);
-        fwd_step<1, DR, 2>(C, r, x);
-        m += rec_dropped(r) ? 0 : 1;
-      });
-  if (nsnp) atomicAdd(&nsnp[p], m);
 }
 
 // Backward sweep inside one chunk + posterior.  post is P x 3 x M (pair-major, as the host writer wants it): row0
 // IBD2, row1 IBD1, row2 IBD0 (decodek2, :1133-1137); -1 where the SNP is dropped (.post writer, :126-133).
 // posterior_x(s) = fwd_x(s) bwd_x(s) / sum_y fwd_y(s) bwd_y(s): every scale factor cancels.
 // Lanes hold consecutive pairs, whose posterior rows lie 3*M doubles apart: results of kTile SNPs are transposed
-// through LDS so that every pair row is written in whole 128-byte lines (64-byte pieces from 8-SNP tiles left
-// half-written lines in L2 and cost DRAM efficiency).  Workgroup = one wave = 64 pairs of one chunk.
-template <bool DR, int TIER>
-__device__ inline void dec_bwd_half(const LaneC &C, const EmisRec (&R)[kGroup], double f0, double f1, double f2, int hb,
-                                    int te, int toff, double &b0, double &b1, double &b2,
-                                    double (&tile)[3][kBwdThreads][kTilePad]) {
-  double F[kGroup][3];
-  {
-    double x[1][3] = {{f0, f1, f2}};
-#pragma unroll
-    for (int u = 0; u < kGroup; u++) {
-      fwd_step<1, DR, TIER>(C, R[u], x);
-      F[u][0] = x[0][0]; F[u][1] = x[0][1]; F[u][2] = x[0][2];
-    }
-  }
-#pragma unroll
-  for (int u = kGroup - 1; u >= 0; u--) {
-    if (hb + u >= te) continue;  // uniform
-    double p0 = F[u][0] * b0, p1 = F[u][1] * b1, p2 = F[u][2] * b2;
-    double sum = (p0 + p1) + p2;
-    double inv = __builtin_amdgcn_rcp(sum);
-    inv = inv * __builtin_fma(-sum, inv, 2.0);
-    inv = inv * __builtin_fma(-sum, inv, 2.0);
-    bool dr = rec_dropped(R[u]);
-    tile[2][threadIdx.x][toff + u] = dr ? -1.0 : p0 * inv;  // row2 = IBD0
-    tile[1][threadIdx.x][toff + u] = dr ? -1.0 : p1 * inv;
-    tile[0][threadIdx.x][toff + u] = dr ? -1.0 : p2 * inv;  // row0 = IBD2
-    bwd_step<DR, TIER>(C, R[u], b0, b1, b2);
-    norm_fast(b0, b1, b2);
-  }
-}
-
+// through LDS so that every pair row is written in whole 128-byte lines.  Workgroup = one wave = 64 pairs of one chunk.
 // OutT = double: post[p][3][M], rows IBD2, IBD1, IBD0 (the reference's dMatrix).  OutT = float: post[p][rows][M] in
 // the order the .post writer takes them (IBD0, IBD1, IBD2; :3771-3782), the first `rows` of them, each value the
 // double result rounded once to float.
 template <bool DR, typename OutT>
 __global__ void __launch_bounds__(kBwdThreads)
-decode_bwd_kernel(const EmisRec *__restrict__ rec, int M, int P, int RP, const double *__restrict__ params, int nlp,
-                  int chunk_len, const double *__restrict__ bend, const double *__restrict__ ckpt,
-                  OutT *__restrict__ post, int rows) {
+decode_bwd_kernel(const double *__restrict__ rec, int M, int P, int RP, int col0, const double *__restrict__ params,
+                  int nlp, int chunk_len, const double *__restrict__ astart, const double *__restrict__ bend,
+                  TileCkpt ck, OutT *__restrict__ post, int rows) {
   __shared__ double tile[3][kBwdThreads][kTilePad];
   int bpc = (P + kBwdThreads - 1) / kBwdThreads;
   int c = blockIdx.x / bpc;
@@ -777,32 +843,38 @@ decode_bwd_kernel(const EmisRec *__restrict__ rec, int M, int P, int RP, const d
   double k0 = 1 - k2 - k1;
   LaneC C = make_lane(a, k2, k1, k0);
   int sb = c * chunk_len, se = min(M, sb + chunk_len);  // sb is a multiple of kTile
+  double a0 = k0, a1 = k1, a2 = k2;
   double b0 = 1, b1 = 1, b2 = 1;
-  if (bend) {
+  if (astart) {
     size_t at = ((size_t)c * nlp + pc) * 3;
+    a0 = astart[at]; a1 = astart[at + 1]; a2 = astart[at + 2];
     b0 = bend[at]; b1 = bend[at + 1]; b2 = bend[at + 2];
   }
-  const size_t stride = (size_t)RP;  // checkpoint rows share the record pitch (no power-of-two row distance)
-  const size_t plane = (size_t)((M + kGroup - 1) / kGroup) * RP;
+  const RecCol col(rec, RP, col0 + pc);
   for (int tb = (se - 1) & ~(kTile - 1); tb >= sb; tb -= kTile) {
     int te = min(se, tb + kTile);
+    Rec R[kTile];
 #pragma unroll
-    for (int part = kTile / kGroup - 1; part >= 0; part--) {
-      int hb = tb + part * kGroup;
-      if (hb >= te) continue;  // uniform: ragged last tile
-      EmisRec R[kGroup];
+    for (int u = 0; u < kTile; u++) R[u] = col.at(min(tb + u, te - 1));
+    ChunkProd X;
+    {
+      const double *qm = ck.m(tb / kTile, pc);
+      const int *qe = ck.e(tb / kTile, pc);
 #pragma unroll
-      for (int u = 0; u < kGroup; u++) R[u] = rec[(size_t)min(hb + u, te - 1) * RP + pc];
-      const double *f = ckpt + (size_t)(hb / kGroup) * stride + pc;
-      double f0 = f[0], f1 = f[plane], f2 = f[2 * plane];
-      int tier = group_tier<kGroup>(C, R);
-      if (tier == 0) dec_bwd_half<DR, 0>(C, R, f0, f1, f2, hb, te, part * kGroup, b0, b1, b2, tile);
-      else if (tier == 1) dec_bwd_half<DR, 1>(C, R, f0, f1, f2, hb, te, part * kGroup, b0, b1, b2, tile);
-      else dec_bwd_half<DR, 2>(C, R, f0, f1, f2, hb, te, part * kGroup, b0, b1, b2, tile);
+      for (int i = 0; i < 9; i++) X.m[i] = qm[i * 64];
+#pragma unroll
+      for (int i = 0; i < 3; i++) X.e[i] = qe[i * 64];
     }
+    double f0 = a0, f1 = a1, f2 = a2;
+    apply_chunk_fwd(f0, f1, f2, X);
+    norm_fast(f0, f1, f2);
+    int tier = group_tier<kTile>(C, R);
+    if (tier == 0) dec_tile<DR, 0>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
+    else if (tier == 1) dec_tile<DR, 1>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
+    else dec_tile<DR, 2>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
     __syncthreads();
     // 3 x 64 x kTile values; consecutive threads write consecutive SNPs of one pair row (128-byte pieces)
-#pragma unroll  // 48 LDS reads in flight: one wave per SIMD, and still faster than a 12-fold unroll at two waves (10.9 against 11.3-12.8 ms)
+#pragma unroll 12
     for (int j = 0; j < 3 * kTile; j++) {
       int idx = j * kBwdThreads + threadIdx.x;
       int e = idx % kTile, pr = (idx / kTile) % kBwdThreads, r = idx / (kTile * kBwdThreads);
@@ -878,8 +950,8 @@ __device__ inline void ref_trans_at(const RefTrans &C, double t, double (&T)[3][
 }
 
 __global__ void __launch_bounds__(256)
-viterbi_kernel(const EmisRec *__restrict__ rec, int M, int P, int RP, const double *__restrict__ params, int double_recom,
-               uint8_t *__restrict__ bp, int8_t *__restrict__ path) {
+viterbi_kernel(const double *__restrict__ rec, int M, int P, int RP, const double *__restrict__ params, int double_recom,
+               uint8_t *__restrict__ bp, int8_t *__restrict__ path) {  // rec: the FULL format (t, S0, S1, S2 planes)
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   double a = params[3 * p], k2 = params[3 * p + 1], k1 = params[3 * p + 2];
@@ -888,9 +960,10 @@ viterbi_kernel(const EmisRec *__restrict__ rec, int M, int P, int RP, const doub
   double v0 = 0, v1 = 0, v2 = 0;
   bool started = false;
   for (int s = 0; s < M; s++) {
-    EmisRec r = rec[(size_t)s * RP + p];
-    if (rec_dropped(r)) continue;
-    double l0 = log(r.s0), l1 = log(r.s1), l2 = log(r.s2);
+    const double *row = rec + (size_t)s * kRecPlanesFull * RP + rec_col_off(p, kRecPlanesFull);
+    const double rt = row[0];
+    if (__builtin_signbit(rt)) continue;
+    double l0 = log(row[64]), l1 = log(row[128]), l2 = log(row[192]);
     if (!started) {
       double mx = fmax(log(k0), fmax(log(k1), log(k2)));
       v0 = mx + l0; v1 = mx + l1; v2 = mx + l2;
@@ -898,7 +971,7 @@ viterbi_kernel(const EmisRec *__restrict__ rec, int M, int P, int RP, const doub
       bp[(size_t)s * P + p] = 0;
     } else {
       double T[3][3];
-      ref_trans_at(C, r.t, T);
+      ref_trans_at(C, rt, T);
       double L[3][3];
       for (int x = 0; x < 3; x++)
         for (int y = 0; y < 3; y++) L[x][y] = log(T[x][y]);
@@ -915,7 +988,7 @@ viterbi_kernel(const EmisRec *__restrict__ rec, int M, int P, int RP, const doub
   int8_t *out = path + (size_t)p * M;
   int cur = started ? vwhich3(v0, v1, v2) : -1;
   for (int s = M - 1; s >= 0; s--) {
-    if (rec_dropped(rec[(size_t)s * RP + p])) { out[s] = -1; continue; }
+    if (__builtin_signbit(rec[(size_t)s * kRecPlanesFull * RP + rec_col_off(p, kRecPlanesFull)])) { out[s] = -1; continue; }
     out[s] = (int8_t)cur;
     cur = (bp[(size_t)s * P + p] >> (2 * cur)) & 3;
   }

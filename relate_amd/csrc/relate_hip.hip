@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <map>
 #include <mutex>
 #include <string>
@@ -120,17 +121,22 @@ struct relate_hip_ctx {
   DBuf<int> dChoose;
   DBuf<uint8_t> dOrder;  // per-SNP preference order of the conditioning depths (windowed staging)
   // device: staged pair block
-  DBuf<EmisRec> dRec;
+  DBuf<double> dRec;            // kRecPlanes planes per SNP row (t, S1/S0, S2/S0), plane pitch recPitch
+  DBuf<double> dRecV;           // the full format (t, S0, S1, S2) of a block: Viterbi and inspection only
   DBuf<int32_t> dPairs;
   std::vector<int32_t> staged;  // pairs of the block currently in dRec (2 ints per pair)
-  int recPitch = 0;             // row pitch of dRec in records (>= pairs of the staged block)
+  std::vector<int32_t> stagedV; // ... in dRecV
+  int recPitch = 0, recPitchV = 0;  // plane pitch in doubles (>= pairs of the staged block)
+  DBuf<double> dScM, dPairM;    // the factor taken out of the records: per-run partial products, per-pair result
+  DBuf<int> dScE, dScN, dPairE; // ... exponents, kept-SNP counts
+  DBuf<int> dNsnp;              // SNPs kept per pair of the staged block
+  std::vector<int> h_nsnp;      // the same on the host
   // device: work
   DBuf<int32_t> dLanePair;
   DBuf<double> dParams, dOut, dPost;
-  DBuf<double> dFwd;  // 3 planes x ceil(M/4) x P forward checkpoints (one per half tile)
+  DBuf<unsigned char> dCk;  // tile checkpoints of the decode (kernels_hmm.hpp, TileCkpt)
   DBuf<uint8_t> dBp;
   DBuf<int8_t> dPath;
-  DBuf<int> dNsnp;
   DBuf<double> dCm, dAstart, dBend;  // chunk products and boundary vectors of the chunked sweeps
   DBuf<int> dCe;
   LaneBufs lanebufs[2];  // pinned lane buffers of the two pair populations of a fit
@@ -189,13 +195,12 @@ void parallel_for(size_t n, F &&fn) {  // fn(begin, end)
   for (auto &x : th) x.join();
 }
 
-// Row pitch of the staged record block: P rounded up to 64 records (2 KiB), then made an odd number of 2 KiB units,
-// so that consecutive SNP rows never lie a power of two apart (HBM channel camping of the strided sweeps).  Small
-// blocks stay dense.
+// Padded pair count of a staged block (a SNP row holds kRecPlanes x this many doubles): P rounded up to whole groups of
+// 64 pairs, and from 256 pairs on to an odd number of groups, so that consecutive SNP rows never lie a power of two
+// apart (HBM channel camping of the strided sweeps).
 inline int rec_pitch(int P) {
-  if (P < 256) return P;
   int u = (P + 63) / 64;
-  if ((u & 1) == 0) u++;
+  if (P >= 256 && (u & 1) == 0) u++;
   return u * 64;
 }
 
@@ -204,22 +209,50 @@ int set_device(relate_hip_t h) {
   return 0;
 }
 
-// Pairs per block such that bytes_per_pair_snp x M x pairs fits in 70 % of the memory that is free now plus `held`
-// bytes the (grow-only) buffers for that purpose already own.
-size_t pair_block_limit(relate_hip_t h, size_t bytes_per_pair_snp, size_t held = 0) {
+// Largest pair block whose buffers fit.  Every MemNeed is one group of grow-only buffers: the bytes it takes per
+// (pair, SNP) and what it holds already; growing a group costs only what it lacks.  The sum of what all groups lack
+// must fit in 70 % of the memory that is free now.
+struct MemNeed {
+  double per_unit;
+  size_t held;
+};
+size_t pair_block_limit(relate_hip_t h, std::initializer_list<MemNeed> needs) {
   size_t freeb = 0, total = 0;
   if (hipMemGetInfo(&freeb, &total) != hipSuccess) freeb = (size_t)8 << 30;
-  size_t budget = (size_t)(0.70 * (double)freeb) + held;
-  size_t per_pair = bytes_per_pair_snp * (size_t)h->M + 256;
-  size_t lim = budget / per_pair;
-  if (lim < 1) lim = 1;
-  if (lim > ((size_t)1 << 22)) lim = (size_t)1 << 22;
-  return lim;
+  const double budget = 0.70 * (double)freeb;
+  auto lacks = [&](size_t L) {
+    double tot = 0;
+    for (const MemNeed &n : needs) {
+      double want = (n.per_unit * (double)h->M + 256.0) * (double)L;
+      if (want > (double)n.held) tot += want - (double)n.held;
+    }
+    return tot;
+  };
+  size_t lo = 1, hi = (size_t)1 << 22;
+  if (lacks(hi) <= budget) return hi;
+  while (hi - lo > 1) {
+    size_t mid = lo + (hi - lo) / 2;
+    if (lacks(mid) <= budget) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
+// bytes per (pair, SNP) of the buffer groups
+constexpr double kRecBytes = 8.0 * kRecPlanes + 0.5;          // records + the per-run partials of the staging kernels
+constexpr double kRecFullBytes = 8.0 * kRecPlanesFull + 2.0;  // full-format records + Viterbi back pointers and path
+constexpr double kCkptBytes = 84.0 / 16 + 0.25;               // tile checkpoints (kernels_hmm.hpp, TileCkpt)
+inline MemNeed need_rec(relate_hip_t h) { return {kRecBytes, h->dRec.cap * sizeof(double)}; }
+inline MemNeed need_ckpt(relate_hip_t h) { return {kCkptBytes, h->dCk.cap}; }
+inline MemNeed need_post(relate_hip_t h, double bytes) { return {bytes, h->dPost.cap * sizeof(double)}; }
+inline MemNeed need_path(relate_hip_t h, bool want) {
+  return {want ? kRecFullBytes : 0.0, h->dRecV.cap * sizeof(double) + h->dBp.cap + h->dPath.cap};
 }
 
-// K4 for a block of pairs (skipped when the same block is already staged)
-int stage_block(relate_hip_t h, const int32_t *pairs, int P) {
-  if ((int)h->staged.size() == 2 * P && std::memcmp(h->staged.data(), pairs, sizeof(int32_t) * 2 * P) == 0) {
+// K4 for a block of pairs (skipped when the same block is already staged).  full: the four-plane format into dRecV
+// (Viterbi, inspection); the block in dRec and its per-pair factors stay as they are.
+int stage_block(relate_hip_t h, const int32_t *pairs, int P, bool full = false) {
+  std::vector<int32_t> &memo = full ? h->stagedV : h->staged;
+  if ((int)memo.size() == 2 * P && std::memcmp(memo.data(), pairs, sizeof(int32_t) * 2 * P) == 0) {
     h->timings[0] = 0;
     return 0;
   }
@@ -228,33 +261,58 @@ int stage_block(relate_hip_t h, const int32_t *pairs, int P) {
     if (a < 0 || a >= h->N || b < 0 || b >= h->N)
       return fail(h, RELATE_E_ARG, "pair index out of range (the data set has " + std::to_string(h->N) + " individuals)");
   }
-  h->staged.clear();
-  h->recPitch = rec_pitch(P);
-  HIPCHK(h, h->dRec.ensure((size_t)h->M * h->recPitch));
+  memo.clear();
+  const int RP = rec_pitch(P);
+  DBuf<double> &R = full ? h->dRecV : h->dRec;
+  (full ? h->recPitchV : h->recPitch) = RP;
+  const int words = 2, chunk = 64;  // SNPs per staging thread: 64 either way
+  const int nruns = h->winMode ? (h->Wt + words - 1) / words : (h->M + chunk - 1) / chunk;
+  HIPCHK(h, R.ensure((size_t)h->M * (full ? kRecPlanesFull : kRecPlanes) * RP));
+  HIPCHK(h, h->dScM.ensure((size_t)nruns * RP));
+  HIPCHK(h, h->dScE.ensure((size_t)nruns * RP));
+  HIPCHK(h, h->dScN.ensure((size_t)nruns * RP));
   HIPCHK(h, h->dPairs.ensure((size_t)2 * P));
   HIPCHK(h, hipMemcpyAsync(h->dPairs.p, pairs, sizeof(int32_t) * 2 * P, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   if (h->winMode) {
-    const int words = 2;  // 64 SNPs per thread
-    unsigned grid = (unsigned)(((size_t)(h->Wt + words - 1) / words) * ((P + 255) / 256));
-    hipLaunchKernelGGL(stage_pairs_win_kernel, dim3(grid), dim3(256), 0, h->stream, h->dGt.p, h->M, h->Wt, h->dPairs.p,
-                       P, words, h->dPos.p, h->dTab1.p, h->dTabD.p, h->dMea.p, h->dChoose.p, h->dOrder.p, h->useLD,
-                       h->o.back, h->back2, h->dRec.p, h->recPitch);
+    unsigned grid = (unsigned)((size_t)nruns * ((P + 255) / 256));
+#define STAGE_WIN(FULL)                                                                                              \
+  hipLaunchKernelGGL(stage_pairs_win_kernel<FULL>, dim3(grid), dim3(256), 0, h->stream, h->dGt.p, h->M, h->Wt,         \
+                     h->dPairs.p, P, words, h->dPos.p, h->dTab1.p, h->dTabD.p, h->dMea.p, h->dChoose.p, h->dOrder.p, \
+                     h->useLD, h->o.back, h->back2, R.p, RP, h->dScM.p, h->dScE.p, h->dScN.p)
+    if (full) STAGE_WIN(true);
+    else STAGE_WIN(false);
+#undef STAGE_WIN
   } else {
-    const int chunk = 64;
-    long nthreads = (long)P * ((h->M + chunk - 1) / chunk);
-    hipLaunchKernelGGL(stage_pairs_kernel, dim3(blocks_for(nthreads, 256)), dim3(256), 0, h->stream, h->dG.p, h->M,
-                       h->W, h->dPairs.p, P, chunk, h->dPos.p, h->dTab1.p, h->dTabL.p, h->dChoose.p, h->dMea.p,
-                       h->dPBA.p, h->dPbA.p, h->dPBa.p, h->dPba.p, h->useLD, h->o.back, h->back2, h->o.epsilon,
-                       h->dRec.p, h->recPitch);
+    long nthreads = (long)P * nruns;
+#define STAGE_GEN(FULL)                                                                                               \
+  hipLaunchKernelGGL(stage_pairs_kernel<FULL>, dim3(blocks_for(nthreads, 256)), dim3(256), 0, h->stream, h->dG.p, h->M, \
+                     h->W, h->dPairs.p, P, chunk, h->dPos.p, h->dTab1.p, h->dTabL.p, h->dChoose.p, h->dMea.p,         \
+                     h->dPBA.p, h->dPbA.p, h->dPBa.p, h->dPba.p, h->useLD, h->o.back, h->back2, h->o.epsilon, R.p,    \
+                     RP, h->dScM.p, h->dScE.p, h->dScN.p)
+    if (full) STAGE_GEN(true);
+    else STAGE_GEN(false);
+#undef STAGE_GEN
   }
   HIPCHK(h, hipGetLastError());
+  if (!full) {
+    HIPCHK(h, h->dPairM.ensure(P));
+    HIPCHK(h, h->dPairE.ensure(P));
+    HIPCHK(h, h->dNsnp.ensure(P));
+    hipLaunchKernelGGL(scale_reduce_kernel, dim3(blocks_for(P, 64)), dim3(64 * kScaleSeg), 0, h->stream, h->dScM.p, h->dScE.p,
+                       h->dScN.p, nruns, RP, P, h->dPairM.p, h->dPairE.p, h->dNsnp.p);
+    HIPCHK(h, hipGetLastError());
+  }
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+  if (!full) {
+    h->h_nsnp.resize(P);
+    HIPCHK(h, hipMemcpyAsync(h->h_nsnp.data(), h->dNsnp.p, sizeof(int) * P, hipMemcpyDeviceToHost, h->stream));
+  }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   float ms = 0;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
   h->timings[0] = ms;
-  h->staged.assign(pairs, pairs + 2 * P);
+  memo.assign(pairs, pairs + 2 * P);
   return 0;
 }
 
@@ -346,6 +404,7 @@ int launch_like(relate_hip_t h, int nl, const LikeIO &io) {
   }
   h->last_chunks[0] = nchunk;
   const bool dr = h->o.double_recom != 0;
+  const PairScale scale{h->dPairM.p, h->dPairE.p};
   if (nchunk == 1) {
     // ring depth by the waves per SIMD this launch can fill (kernels_hmm.hpp, like_kernel)
     const long simd_lanes = 256L * 4 * 64;
@@ -366,8 +425,8 @@ int launch_like(relate_hip_t h, int nl, const LikeIO &io) {
         hipLaunchKernelGGL((like_halves_kernel<false, 4>), grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch,
                            io.map, io.params, nl, nlp, h->o.alim[1], part);
       HIPCHK(h, hipGetLastError());
-      hipLaunchKernelGGL(like_join_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, part, io.params, nl,
-                         nlp, h->o.alim[1], io.out);
+      hipLaunchKernelGGL(like_join_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, part, io.map, scale,
+                         io.params, nl, nlp, h->o.alim[1], io.out);
       HIPCHK(h, hipGetLastError());
       return 0;
     }
@@ -375,7 +434,7 @@ int launch_like(relate_hip_t h, int nl, const LikeIO &io) {
     dim3 grid(blocks_for(nl, 256)), block(256);
 #define LAUNCH_LIKE(DR, NB)                                                                                   \
   hipLaunchKernelGGL((like_kernel<DR, NB>), grid, block, 0, h->stream, h->dRec.p, h->M, h->recPitch, io.map, \
-                     io.params, nl, h->o.alim[1], io.out)
+                     scale, io.params, nl, h->o.alim[1], io.out)
     if (dr) {
       if (nbuf == 6) LAUNCH_LIKE(true, 6);
       else if (nbuf == 4) LAUNCH_LIKE(true, 4);
@@ -400,14 +459,14 @@ int launch_like(relate_hip_t h, int nl, const LikeIO &io) {
   }
   dim3 grid((unsigned)((size_t)(nlp / 256) * nchunk));
   if (dr)
-    hipLaunchKernelGGL(chunk_matrix_kernel<true>, grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch, io.map,
-                       io.params, nl, nlp, nchunk, clen, h->o.alim[1], 1, O);
+    hipLaunchKernelGGL((chunk_matrix_kernel<true, false>), grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch,
+                       io.map, io.params, nl, nlp, nchunk, clen, h->o.alim[1], 1, O, TileCkpt{nullptr, 0}, 0);
   else
-    hipLaunchKernelGGL(chunk_matrix_kernel<false>, grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch, io.map,
-                       io.params, nl, nlp, nchunk, clen, h->o.alim[1], 1, O);
+    hipLaunchKernelGGL((chunk_matrix_kernel<false, false>), grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch,
+                       io.map, io.params, nl, nlp, nchunk, clen, h->o.alim[1], 1, O, TileCkpt{nullptr, 0}, 0);
   HIPCHK(h, hipGetLastError());
-  hipLaunchKernelGGL(like_combine_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, O, io.params, nl, nlp,
-                     nchunk, h->o.alim[1], io.out);
+  hipLaunchKernelGGL(like_combine_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, O, io.map, scale,
+                     io.params, nl, nlp, nchunk, h->o.alim[1], dr ? 1 : 0, io.out);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -509,7 +568,7 @@ struct FitPop {
     for (Run *r : active) delete r;
   }
   void init(int p0_, int P_, const relate_opts *o_, const FitSpec &S_, const double *starts_, long pair_base_,
-            LaneBufs *B_) {
+            LaneBufs *B_, const int *nsnp) {
     p0 = p0_; P = P_; o = o_; S = S_; starts = starts_; pair_base = pair_base_; B = B_;
     n = S.nvar();
     R = std::max(1, o->timesToRun);
@@ -519,6 +578,7 @@ struct FitPop {
       ms[p].timesToConverge = o->timesToConverge;
       ms[p].timesToRun = R;
       ms[p].convTol = o->convTol;
+      if (nsnp[p0 + p] == 0) ms[p].finished = true;  // nothing to fit: the pair shares no SNP (status RELATE_E_NOSNP)
     }
     if (!starts) {
       rng.reserve(P);
@@ -711,6 +771,9 @@ int fit_block(relate_hip_t h, int P, long pair_base, const double *starts, relat
   for (int p = 0; p < P; p++) {
     out[p] = relate_fit{};
     out[p].status = 0;
+    out[p].nsnp = h->h_nsnp[p];
+    // the reference stops here: "pair doesn't share 1 non-missing SNP" (src/relateHMM.cpp:3415-3421)
+    if (h->h_nsnp[p] == 0) out[p].status = RELATE_E_NOSNP;
   }
   if (o.doPar) {  // likelihood at the user's parameters, no optimisation (:3484-3510)
     std::vector<int32_t> lp;
@@ -755,7 +818,7 @@ int fit_block(relate_hip_t h, int P, long pair_base, const double *starts, relat
   FitPop pop[2];
   for (int k = 0; k < npop; k++) {
     int b = (int)((long)P * k / npop), e = (int)((long)P * (k + 1) / npop);
-    pop[k].init(b, e - b, &o, S, starts, pair_base, &h->lanebufs[k]);
+    pop[k].init(b, e - b, &o, S, starts, pair_base, &h->lanebufs[k], h->h_nsnp.data());
   }
   auto start = [&](FitPop &F) -> int {
     F.inflight = false;
@@ -841,51 +904,49 @@ int copy_to_host(relate_hip_t h, void *dst, const void *src, size_t bytes) {
   return drain(np - 1);
 }
 
-// K6 launches for the staged block with params already in dParams; posteriors left in dPost
+// K6 launches for pairs [p0, p0 + P) of the staged block with their params already in dParams; posteriors left in dPost
 // (f32_rows: 0 = doubles, P x 3 x M; 1..3 = floats, P x f32_rows x M in writer order, in the same buffer)
-int launch_decode(relate_hip_t h, int P, int f32_rows = 0) {
+int launch_decode(relate_hip_t h, int p0, int P, int f32_rows = 0) {
   const int M = h->M;
   int nchunk, clen;
   pick_chunks(M, P, h->single_sweep_lanes, 256, h->slots_decode, 1, &nchunk, &clen);
   h->last_chunks[1] = nchunk;
   const bool dr = h->o.double_recom != 0;
   const int nlp = pad256(P);
+  const double *rec = h->dRec.p;
+  const int RP = h->recPitch;
+  const size_t ntile = (size_t)(M + 15) / 16;
+  const size_t tile_stride = (size_t)((P + 63) / 64) * kCkptGroupBytes;
+  HIPCHK(h, h->dCk.ensure(ntile * tile_stride));
+  const TileCkpt ck{h->dCk.p, tile_stride};
+  size_t n = (size_t)nlp * nchunk;
+  ChunkOut O;
+  int rc = ensure_chunk_buffers(h, n, &O);
+  if (rc) return rc;
   const double *astart = nullptr, *bend = nullptr;
-  HIPCHK(h, hipMemsetAsync(h->dNsnp.p, 0, sizeof(int) * P, h->stream));
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   dim3 grid((unsigned)((size_t)(nlp / 256) * nchunk));
+  if (dr)
+    hipLaunchKernelGGL((chunk_matrix_kernel<true, true>), grid, dim3(256), 0, h->stream, rec, M, RP, LaneMap{nullptr, 1},
+                       h->dParams.p, P, nlp, nchunk, clen, h->o.alim[1], 0, O, ck, p0);
+  else
+    hipLaunchKernelGGL((chunk_matrix_kernel<false, true>), grid, dim3(256), 0, h->stream, rec, M, RP, LaneMap{nullptr, 1},
+                       h->dParams.p, P, nlp, nchunk, clen, h->o.alim[1], 0, O, ck, p0);
+  HIPCHK(h, hipGetLastError());
   if (nchunk > 1) {
-    size_t n = (size_t)nlp * nchunk;
-    ChunkOut O;
-    int rc = ensure_chunk_buffers(h, n, &O);
-    if (rc) return rc;
     HIPCHK(h, h->dAstart.ensure((size_t)3 * n));
     HIPCHK(h, h->dBend.ensure((size_t)3 * n));
-    if (dr)
-      hipLaunchKernelGGL(chunk_matrix_kernel<true>, grid, dim3(256), 0, h->stream, h->dRec.p, M, h->recPitch,
-                         LaneMap{nullptr, 1}, h->dParams.p, P, nlp, nchunk, clen, h->o.alim[1], 0, O);
-    else
-      hipLaunchKernelGGL(chunk_matrix_kernel<false>, grid, dim3(256), 0, h->stream, h->dRec.p, M, h->recPitch,
-                         LaneMap{nullptr, 1}, h->dParams.p, P, nlp, nchunk, clen, h->o.alim[1], 0, O);
-    HIPCHK(h, hipGetLastError());
     hipLaunchKernelGGL(decode_combine_kernel, dim3(blocks_for(P, 256)), dim3(256), 0, h->stream, O, h->dParams.p, P,
                        nlp, nchunk, h->dAstart.p, h->dBend.p);
     HIPCHK(h, hipGetLastError());
     astart = h->dAstart.p;
     bend = h->dBend.p;
   }
-  if (dr)
-    hipLaunchKernelGGL(decode_fwd_kernel<true>, grid, dim3(256), 0, h->stream, h->dRec.p, M, P, h->recPitch, h->dParams.p, nlp, clen,
-                       astart, h->dFwd.p, h->dNsnp.p);
-  else
-    hipLaunchKernelGGL(decode_fwd_kernel<false>, grid, dim3(256), 0, h->stream, h->dRec.p, M, P, h->recPitch, h->dParams.p, nlp,
-                       clen, astart, h->dFwd.p, h->dNsnp.p);
-  HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
   dim3 bgrid((unsigned)((size_t)((P + kBwdThreads - 1) / kBwdThreads) * nchunk));
-#define LAUNCH_BWD(DRV, T, OUT, ROWS)                                                                                  \
-  hipLaunchKernelGGL((decode_bwd_kernel<DRV, T>), bgrid, dim3(kBwdThreads), 0, h->stream, h->dRec.p, M, P, h->recPitch, \
-                     h->dParams.p, nlp, clen, bend, h->dFwd.p, OUT, ROWS)
+#define LAUNCH_BWD(DRV, T, OUT, ROWS)                                                                              \
+  hipLaunchKernelGGL((decode_bwd_kernel<DRV, T>), bgrid, dim3(kBwdThreads), 0, h->stream, rec, M, P, RP, p0,         \
+                     h->dParams.p, nlp, clen, astart, bend, ck, OUT, ROWS)
   if (f32_rows) {
     float *pf = reinterpret_cast<float *>(h->dPost.p);
     if (dr) LAUNCH_BWD(true, float, pf, f32_rows);
@@ -900,18 +961,18 @@ int launch_decode(relate_hip_t h, int P, int f32_rows = 0) {
   return 0;
 }
 
-int decode_block(relate_hip_t h, int P, const double *params, double *post, int8_t *path, int *nsnp_out,
-                 bool copy_back, float *post32 = nullptr, int f32_rows = 0) {
+// Decode (and Viterbi) of pairs [p0, p0 + P) of the staged block; `pairs` = those P pairs (needed to stage the full
+// format when a path is wanted).
+int decode_block(relate_hip_t h, const int32_t *pairs, int p0, int P, const double *params, double *post, int8_t *path,
+                 int *nsnp_out, bool copy_back, float *post32 = nullptr, int f32_rows = 0) {
   const int M = h->M;
   HIPCHK(h, h->dParams.ensure((size_t)3 * P));
-  HIPCHK(h, h->dNsnp.ensure(P));
   HIPCHK(h, hipMemcpyAsync(h->dParams.p, params, sizeof(double) * 3 * P, hipMemcpyHostToDevice, h->stream));
-  if (post || post32 || nsnp_out || !copy_back) {
-    HIPCHK(h, h->dFwd.ensure((size_t)3 * ((M + 3) / 4) * h->recPitch));
+  if (nsnp_out) std::memcpy(nsnp_out, h->h_nsnp.data() + p0, sizeof(int) * P);  // counted by the staging kernel
+  if (post || post32 || !copy_back) {
     HIPCHK(h, h->dPost.ensure(post32 ? ((size_t)f32_rows * M * P + 1) / 2 : (size_t)3 * M * P));
-    int rc = launch_decode(h, P, post32 ? f32_rows : 0);
+    int rc = launch_decode(h, p0, P, post32 ? f32_rows : 0);
     if (rc) return rc;
-    if (nsnp_out) HIPCHK(h, hipMemcpyAsync(nsnp_out, h->dNsnp.p, sizeof(int) * P, hipMemcpyDeviceToHost, h->stream));
     if (copy_back && post) {
       rc = copy_to_host(h, post, h->dPost.p, sizeof(double) * 3 * M * P);
       if (rc) return rc;
@@ -928,12 +989,14 @@ int decode_block(relate_hip_t h, int P, const double *params, double *post, int8
     h->timings[3] += b;
   }
   if (path) {
+    int rc = stage_block(h, pairs, P, true);  // the Viterbi works on log S of every state: full format, own buffer
+    if (rc) return rc;
     HIPCHK(h, h->dBp.ensure((size_t)M * P));
     HIPCHK(h, h->dPath.ensure((size_t)M * P));
-    hipLaunchKernelGGL(viterbi_kernel, dim3(blocks_for(P, 256)), dim3(256), 0, h->stream, h->dRec.p, M, P, h->recPitch,
+    hipLaunchKernelGGL(viterbi_kernel, dim3(blocks_for(P, 256)), dim3(256), 0, h->stream, h->dRecV.p, M, P, h->recPitchV,
                        h->dParams.p, h->o.double_recom, h->dBp.p, h->dPath.p);
     HIPCHK(h, hipGetLastError());
-    int rc = copy_to_host(h, path, h->dPath.p, (size_t)M * P);
+    rc = copy_to_host(h, path, h->dPath.p, (size_t)M * P);
     if (rc) return rc;
   }
   return 0;
@@ -970,12 +1033,12 @@ int relate_hip_create(relate_hip_t *out, int device_id) {
     int ncu = 256;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
       ncu = prop.multiProcessorCount;
-    long sc = wave_slots(chunk_matrix_kernel<false>, 256, ncu);
-    long sf = wave_slots(decode_fwd_kernel<false>, 256, ncu);
+    long sc = wave_slots(chunk_matrix_kernel<false, false>, 256, ncu);
+    long sa = wave_slots(chunk_matrix_kernel<false, true>, 256, ncu);
     long sb = wave_slots(decode_bwd_kernel<false, double>, kBwdThreads, ncu);
     h->slots_like = sc;
-    // decode launches (P / 64) waves per chunk in each of its three sweeps
-    h->slots_decode = lcm(lcm(sc, sf), sb);
+    // decode launches (P / 64) waves per chunk in each of its two sweeps
+    h->slots_decode = lcm(sa, sb);
   }
   {
     // the no-alloc entry point's scratch: every GPU holds its own copy of the array at its own address
@@ -996,7 +1059,8 @@ int relate_hip_destroy(relate_hip_t h) {
   h->dPBa.release(); h->dPba.release(); h->dTab1.release(); h->dTabL.release(); h->dChoose.release();
   h->dGt.release(); h->dTabD.release(); h->dOrder.release();
   h->dRec.release(); h->dPairs.release(); h->dLanePair.release(); h->dParams.release(); h->dOut.release();
-  h->dPost.release(); h->dFwd.release(); h->dBp.release(); h->dPath.release(); h->dNsnp.release();
+  h->dPost.release(); h->dCk.release(); h->dBp.release(); h->dPath.release(); h->dNsnp.release();
+  h->dRecV.release(); h->dScM.release(); h->dScE.release(); h->dScN.release(); h->dPairM.release(); h->dPairE.release();
   h->dCm.release(); h->dAstart.release(); h->dBend.release(); h->dCe.release();
   h->lanebufs[0].release(); h->lanebufs[1].release();
   for (int i = 0; i < 2; i++) {
@@ -1085,6 +1149,7 @@ int relate_hip_load(relate_hip_t h, const uint8_t *geno, int N, int M_raw, const
   h->loaded = true;
   h->ready = false;
   h->staged.clear();
+  h->stagedV.clear();
   return RELATE_OK;
 }
 
@@ -1114,6 +1179,7 @@ int relate_hip_load_bed(relate_hip_t h, const uint8_t *bed, int N, int n_snp_bed
   h->loaded = true;
   h->ready = false;
   h->staged.clear();
+  h->stagedV.clear();
   return RELATE_OK;
 }
 
@@ -1320,6 +1386,7 @@ int relate_hip_precalc(relate_hip_t h, int *keep_out, int *M_out) {
 #undef PCHK
   h->ready = true;
   h->staged.clear();
+  h->stagedV.clear();
   if (keep_out) std::memcpy(keep_out, h->keep.data(), sizeof(int) * Mraw);
   if (M_out) *M_out = M;
   return RELATE_OK;
@@ -1363,18 +1430,19 @@ int relate_hip_pair_emissions(relate_hip_t h, int ind1, int ind2, int *keep, dou
   int rc = require_ready(h);
   if (rc) return rc;
   int32_t pr[2] = {ind1, ind2};
-  rc = stage_block(h, pr, 1);
+  rc = stage_block(h, pr, 1, true);  // full format: t, S0, S1, S2 planes of one 64-pair group
   if (rc) return rc;
-  std::vector<EmisRec> r(h->M);
-  HIPCHK(h, hipMemcpy(r.data(), h->dRec.p, sizeof(EmisRec) * h->M, hipMemcpyDeviceToHost));
+  std::vector<double> r((size_t)h->M * kRecPlanesFull * h->recPitchV);
+  HIPCHK(h, hipMemcpy(r.data(), h->dRecV.p, sizeof(double) * r.size(), hipMemcpyDeviceToHost));
   for (int s = 0; s < h->M; s++) {
-    bool k = !std::signbit(r[s].t);  // dropped SNPs carry t = -0.0
+    const double *q = &r[(size_t)s * kRecPlanesFull * h->recPitchV];  // pair 0 of group 0: planes 64 doubles apart
+    bool k = !std::signbit(q[0]);  // dropped SNPs carry t = -0.0
     if (keep) keep[s] = k ? 1 : 0;
-    if (t) t[s] = k ? r[s].t : -1.0;
+    if (t) t[s] = k ? q[0] : -1.0;
     if (S) {
-      S[s] = k ? r[s].s0 : 0;
-      S[(size_t)h->M + s] = k ? r[s].s1 : 0;
-      S[(size_t)2 * h->M + s] = k ? r[s].s2 : 0;
+      S[s] = k ? q[64] : 0;
+      S[(size_t)h->M + s] = k ? q[128] : 0;
+      S[(size_t)2 * h->M + s] = k ? q[192] : 0;
     }
   }
   return RELATE_OK;
@@ -1385,7 +1453,7 @@ int relate_hip_like(relate_hip_t h, const int32_t *pairs, int P, const double *p
   if (rc) return rc;
   if (!pairs || !params || !negloglik || P < 0 || E < 1) return fail(h, RELATE_E_ARG, "bad arguments");
   h->timings[1] = 0;
-  size_t lim = pair_block_limit(h, sizeof(EmisRec), h->dRec.cap * sizeof(EmisRec));
+  size_t lim = pair_block_limit(h, {need_rec(h)});
   std::vector<int32_t> lp;
   for (long b0 = 0; b0 < P; b0 += (long)lim) {
     int pb = (int)std::min<long>((long)lim, P - b0);
@@ -1423,7 +1491,7 @@ int relate_hip_fit(relate_hip_t h, const int32_t *pairs, int P, const double *st
   if (!pairs || !out || P < 0) return fail(h, RELATE_E_ARG, "bad arguments");
   h->timings[1] = 0;
   if (conv_out) std::memset(conv_out, 0, sizeof(double) * (size_t)P * std::max(1, h->o.timesToRun) * 4);
-  size_t lim = pair_block_limit(h, sizeof(EmisRec), h->dRec.cap * sizeof(EmisRec));
+  size_t lim = pair_block_limit(h, {need_rec(h)});
   for (long b0 = 0; b0 < P; b0 += (long)lim) {
     int pb = (int)std::min<long>((long)lim, P - b0);
     rc = stage_block(h, pairs + 2 * b0, pb);
@@ -1440,13 +1508,13 @@ int relate_hip_decode(relate_hip_t h, const int32_t *pairs, int P, const double 
   if (rc) return rc;
   if (!pairs || !params || P < 0) return fail(h, RELATE_E_ARG, "bad arguments");
   h->timings[2] = h->timings[3] = 0;
-  size_t lim = pair_block_limit(h, sizeof(EmisRec) + 3 * sizeof(double) + 8,
-                                h->dRec.cap * sizeof(EmisRec) + (h->dPost.cap + h->dFwd.cap) * sizeof(double));
+  // every buffer group counts for what it lacks: records, posteriors, tile checkpoints, and the Viterbi's own buffers
+  size_t lim = pair_block_limit(h, {need_rec(h), need_post(h, post ? 24.0 : 0.0), need_ckpt(h), need_path(h, path != nullptr)});
   for (long b0 = 0; b0 < P; b0 += (long)lim) {
     int pb = (int)std::min<long>((long)lim, P - b0);
     rc = stage_block(h, pairs + 2 * b0, pb);
     if (rc) return rc;
-    rc = decode_block(h, pb, params + 3 * b0, post ? post + (size_t)b0 * 3 * h->M : nullptr,
+    rc = decode_block(h, pairs + 2 * b0, 0, pb, params + 3 * b0, post ? post + (size_t)b0 * 3 * h->M : nullptr,
                       path ? path + (size_t)b0 * h->M : nullptr, nsnp_out ? nsnp_out + b0 : nullptr, true);
     if (rc) return rc;
   }
@@ -1459,14 +1527,13 @@ int relate_hip_decode_f32(relate_hip_t h, const int32_t *pairs, int P, const dou
   if (rc) return rc;
   if (!pairs || !params || !post || P < 0 || rows < 1 || rows > 3) return fail(h, RELATE_E_ARG, "bad arguments");
   h->timings[2] = h->timings[3] = 0;
-  size_t lim = pair_block_limit(h, sizeof(EmisRec) + rows * sizeof(float) + 8,
-                                h->dRec.cap * sizeof(EmisRec) + (h->dPost.cap + h->dFwd.cap) * sizeof(double));
+  size_t lim = pair_block_limit(h, {need_rec(h), need_post(h, 4.0 * rows), need_ckpt(h)});
   for (long b0 = 0; b0 < P; b0 += (long)lim) {
     int pb = (int)std::min<long>((long)lim, P - b0);
     rc = stage_block(h, pairs + 2 * b0, pb);
     if (rc) return rc;
-    rc = decode_block(h, pb, params + 3 * b0, nullptr, nullptr, nsnp_out ? nsnp_out + b0 : nullptr, true,
-                      post + (size_t)b0 * rows * h->M, rows);
+    rc = decode_block(h, pairs + 2 * b0, 0, pb, params + 3 * b0, nullptr, nullptr, nsnp_out ? nsnp_out + b0 : nullptr,
+                      true, post + (size_t)b0 * rows * h->M, rows);
     if (rc) return rc;
   }
   return RELATE_OK;
@@ -1480,32 +1547,29 @@ int relate_hip_run_pairs(relate_hip_t h, const int32_t *pairs, int P, const doub
   h->timings[1] = h->timings[2] = h->timings[3] = 0;
   // The fit wants as many pairs in flight as the records allow (its launches are single sweeps only with tens of
   // thousands of lanes); the posteriors of a fitted block are then decoded in sub-blocks sized to what is left for
-  // the 30 B per (pair, SNP) of posterior and checkpoint buffers (a sub-block is re-staged into the same records).
-  size_t lim = pair_block_limit(h, sizeof(EmisRec), h->dRec.cap * sizeof(EmisRec));
+  // the posterior and checkpoint buffers, each a range of columns of the records already staged.
+  size_t lim = pair_block_limit(h, {need_rec(h)});
   std::vector<double> par;
-  std::vector<int> ns;
   for (long b0 = 0; b0 < P; b0 += (long)lim) {
     int pb = (int)std::min<long>((long)lim, P - b0);
     rc = stage_block(h, pairs + 2 * b0, pb);
     if (rc) return rc;
     rc = fit_block(h, pb, b0, starts, out + b0, nullptr);
     if (rc) return rc;
-    size_t dlim = pair_block_limit(h, 3 * sizeof(double) + 8, (h->dPost.cap + h->dFwd.cap) * sizeof(double));
+    if (!post && !path) continue;
+    size_t dlim = pair_block_limit(h, {need_post(h, post ? 24.0 : 0.0), need_ckpt(h), need_path(h, path != nullptr)});
     if (dlim > (size_t)pb) dlim = pb;
     for (long c0 = 0; c0 < pb; c0 += (long)dlim) {
       int pc = (int)std::min<long>((long)dlim, pb - c0);
-      rc = stage_block(h, pairs + 2 * (b0 + c0), pc);
-      if (rc) return rc;
       par.resize((size_t)3 * pc);
-      ns.resize(pc);
       for (int p = 0; p < pc; p++) {
         const relate_fit &f = out[b0 + c0 + p];
         par[3 * p] = f.a; par[3 * p + 1] = f.k2; par[3 * p + 2] = f.k1;
       }
-      rc = decode_block(h, pc, par.data(), post ? post + (size_t)(b0 + c0) * 3 * h->M : nullptr,
-                        path ? path + (size_t)(b0 + c0) * h->M : nullptr, ns.data(), true);
+      rc = decode_block(h, pairs + 2 * (b0 + c0), (int)c0, pc, par.data(),
+                        post ? post + (size_t)(b0 + c0) * 3 * h->M : nullptr,
+                        path ? path + (size_t)(b0 + c0) * h->M : nullptr, nullptr, true);
       if (rc) return rc;
-      for (int p = 0; p < pc; p++) out[b0 + c0 + p].nsnp = ns[p];
     }
   }
   return RELATE_OK;
@@ -1595,7 +1659,7 @@ int relate_hip_bench_decode(relate_hip_t h, const int32_t *pairs, int P, const d
   if (rc) return rc;
   h->timings[2] = h->timings[3] = 0;
   for (int r = 0; r < reps; r++) {
-    rc = decode_block(h, P, params, nullptr, nullptr, nullptr, false);
+    rc = decode_block(h, pairs, 0, P, params, nullptr, nullptr, nullptr, false);
     if (rc) return rc;
   }
   if (ms_fwd_out) *ms_fwd_out = h->timings[2] / reps;
