@@ -2,12 +2,14 @@
 // Replaces error/errorNoLD/emission2_new/errorLD/LDemission_new/LD2_new and the per-pair table
 // re-indexing remove_cross/getHighestId (src/relateHMM.cpp:2776-2975, 850-971, 481-497).  gfx950 only.
 //
-// Emission records live SNP-major in HBM, 24 B per pair and SNP: t, S_ibd1 / S_ibd0, S_ibd2 / S_ibd0.  A SNP row holds
-// the pairs of the staged block in groups of 64 (one wave); a group keeps its three values as three planes of 64
-// doubles back to back (1 536 B), so every plane access of a wave is 512 contiguous bytes, the three planes of a record
-// are one immediate offset apart, and a wave's record traffic per SNP is one contiguous piece:
-//     rec[s * 3 * RP + (p / 64) * 192 + c * 64 + p % 64],   c = 0: t, 1: S1/S0, 2: S2/S0
-// (RP = pairs rounded up to a multiple of 64, chosen by the host so that consecutive SNP rows do not lie a power of
+// Emission records live SNP-major in HBM, 24 B per pair and SNP: t, S_ibd1 / S_ibd0, S_ibd2 / S_ibd0.  Two consecutive
+// SNPs share a row, and a row holds the pairs of the staged block in groups of 64 (one wave); a group keeps its three
+// values as three planes of 64 x {SNP 2h, SNP 2h+1} (16 B per pair and plane, 3 072 B per group), so a wave fetches two
+// records of each of its pairs with three 16-byte loads -- 1.5 vector-memory instructions per record, every one
+// a contiguous KiB (the address unit does ~20 cycles of work per wave instruction whatever its width, and the sweeps
+// are bound by it before they are bound by bytes):
+//     rec[(s / 2) * 6 * RP + (p / 64) * 384 + c * 128 + (p % 64) * 2 + s % 2],   c = 0: t, 1: S1/S0, 2: S2/S0
+// (RP = pairs rounded up to a multiple of 64, chosen by the host so that consecutive rows do not lie a power of
 // two apart).  Emissions matter to the recursions only up to a per-SNP factor: the factor S_ibd0 is
 // taken out here, multiplied up per pair (mantissa and power-of-two exponent, scale_reduce_kernel) and added to the
 // log-likelihood once; it cancels in posteriors.  A SNP dropped for the pair (a missing genotype) is {-0.0, 1, 1}
@@ -20,8 +22,10 @@
 namespace relate {
 
 static constexpr int kRecPlanes = 3, kRecPlanesFull = 4;
-// offset in doubles of pair column `col` inside a SNP row of `npl` planes; plane c is c * 64 further
-__host__ __device__ inline size_t rec_col_off(int col, int npl) { return (size_t)(col >> 6) * (npl * 64) + (col & 63); }
+// offset in doubles of SNP s, pair column col in a block of npl planes and padded pair count RP; plane c is c * 128 further
+__host__ __device__ inline size_t rec_off(int s, int col, int npl, int RP) {
+  return (size_t)(s >> 1) * (2 * npl) * RP + (size_t)(col >> 6) * (npl * 128) + (col & 63) * 2 + (s & 1);
+}
 
 // A table entry holds {S_ibd0, S_ibd1 / S_ibd0, S_ibd2 / S_ibd0} (correctly rounded divisions, once per entry), so the
 // staging kernel divides nothing.  An all-zero emission (conditioning row beyond the data) stays all zero.
@@ -43,24 +47,28 @@ struct ScaleAcc {
   }
 };
 
-// One staged record leaves a lane: planes of row s, pair column p.  FULL: t, S0, S1, S2; else t, S1/S0, S2/S0.
-// state: 0 dropped, 1/2 kept with entry {s0, r1, r2}, 3 all-zero emission.
+// One staged record of a lane.  state: 0 dropped, 1/2 kept with entry {s0, r1, r2}, 3 all-zero emission.  Returns the
+// values of the planes (FULL: t, S0, S1, S2; else t, S1/S0, S2/S0) and folds the factor into acc.
 template <bool FULL>
-__device__ inline void put_record(double *__restrict__ rec, int RP, int s, int p, bool live, int state, double t,
-                                  double s0, double r1, double r2, ScaleAcc &acc, int &nkept) {
-  constexpr int NPL = FULL ? kRecPlanesFull : kRecPlanes;
-  double *row = rec + (size_t)s * NPL * RP + rec_col_off(p, NPL);
+__device__ inline void make_record(int state, double t, double s0, double r1, double r2, ScaleAcc &acc, int &nkept,
+                                   double (&out)[FULL ? 4 : 3]) {
   if (state == 0) { t = -0.0; s0 = 1; r1 = 1; r2 = 1; }
   else if (state == 3) { s0 = 0; r1 = 0; r2 = 0; }
   nkept += state != 0;
   acc.m *= s0;
-  if (!live) return;
-  row[0] = t;
-  if (FULL) {
-    row[64] = s0; row[128] = r1 * s0; row[192] = r2 * s0;
-  } else {
-    row[64] = r1; row[128] = r2;
-  }
+  out[0] = t;
+  if (FULL) { out[1] = s0; out[2] = r1 * s0; out[3] = r2 * s0; }
+  else { out[1] = r1; out[2] = r2; }
+}
+template <bool FULL>
+__device__ inline void put_record(double *__restrict__ rec, int RP, int s, int p, int state, double t, double s0,
+                                  double r1, double r2, ScaleAcc &acc, int &nkept) {
+  constexpr int NPL = FULL ? kRecPlanesFull : kRecPlanes;
+  double v[NPL];
+  make_record<FULL>(state, t, s0, r1, r2, acc, nkept, v);
+  double *q = rec + rec_off(s, p, NPL, RP);
+#pragma unroll
+  for (int c = 0; c < NPL; c++) q[c * 128] = v[c];
 }
 
 // P(observed code o in 1..3 | true genotype index tr in 0..2): error(), src/relateHMM.cpp:2828-2855.
@@ -304,7 +312,7 @@ __global__ void stage_pairs_kernel(const uint64_t *__restrict__ G, int M, int W,
       last = s;
       if (run < back) run++;
     }
-    put_record<FULL>(rec, RP, s, p, true, state, t, e0, e1, e2, acc, nkept);
+    put_record<FULL>(rec, RP, s, p, state, t, e0, e1, e2, acc, nkept);
     if ((s & 7) == 7) acc.fold();
   }
   acc.fold();
@@ -545,12 +553,24 @@ stage_pairs_win_kernel(const uint64_t *__restrict__ Gt, int M, int Wt, const int
         v[u][0] = e[u][0]; v[u][1] = e[u][1]; v[u][2] = e[u][2];
       }
 #pragma unroll
-      for (int u = 0; u < kBatch; u++) {
-        int k = k0 + u;
-        if (k >= kmax) continue;  // uniform
+      for (int u = 0; u < kBatch; u += 2) {  // two SNPs = one 16-byte element per plane
+        constexpr int NPL = FULL ? kRecPlanesFull : kRecPlanes;
+        if (k0 + u >= kmax) continue;  // uniform
+        double va[NPL], vb[NPL];
         double d = tpos[u] - lpos[u];
-        double tt = state[u] == 1 ? 0.0 : (d < 0 ? 10000000.0 : d);
-        put_record<FULL>(rec, RP, w * 32 + k, p, true, state[u], tt, v[u][0], v[u][1], v[u][2], acc, nkept);
+        make_record<FULL>(state[u], state[u] == 1 ? 0.0 : (d < 0 ? 10000000.0 : d), v[u][0], v[u][1], v[u][2], acc,
+                          nkept, va);
+        double *q = rec + rec_off(w * 32 + k0 + u, p, NPL, RP);
+        if (k0 + u + 1 < kmax) {  // uniform
+          d = tpos[u + 1] - lpos[u + 1];
+          make_record<FULL>(state[u + 1], state[u + 1] == 1 ? 0.0 : (d < 0 ? 10000000.0 : d), v[u + 1][0], v[u + 1][1],
+                            v[u + 1][2], acc, nkept, vb);
+#pragma unroll
+          for (int c = 0; c < NPL; c++) *(double2 *)(q + c * 128) = double2{va[c], vb[c]};
+        } else {
+#pragma unroll
+          for (int c = 0; c < NPL; c++) q[c * 128] = va[c];
+        }
       }
       if ((k0 & 4) == 4) acc.fold();  // every 8 records
     }

@@ -17,8 +17,8 @@
 // polynomials in -a t with per-lane coefficients (LaneC); a forward step is then 13 + 14 FP64 instructions per
 // vector.  like() is reproduced to <= 1e-13 relative (tests/test_gpu_parity.py).
 //
-// Records (kernels_emis.hpp).  t, S_ibd1/S_ibd0, S_ibd2/S_ibd0 (24 B per pair and SNP) as three planes of 64 doubles per
-// group of 64 pairs and SNP row.  The recursions need emissions only up to a per-SNP factor: S_ibd0 is taken out
+// Records (kernels_emis.hpp).  t, S_ibd1/S_ibd0, S_ibd2/S_ibd0 (24 B per pair and SNP) as three planes per group of 64
+// pairs, two consecutive SNPs per 16-byte element: three wave loads bring two records of every lane.  The recursions need emissions only up to a per-SNP factor: S_ibd0 is taken out
 // at staging time, its product per pair (mantissa sc_m, exponent sc_e) enters the log-likelihood once at the end and
 // cancels in posteriors -- a quarter of the bytes of every sweep and one multiply per vector-step less.  A SNP dropped
 // for the pair is {-0.0, 1, 1}: T(0) = I exactly, so the step is the identity and no lane ever branches on it; the
@@ -51,17 +51,31 @@ struct Rec {
 // plus the lane's byte offset.
 struct RecCol {
   const double *__restrict__ base;
-  size_t row;    // row stride in doubles (3 planes x padded pairs)
+  size_t row;    // stride in doubles of a row of two SNPs (3 planes x padded pairs x 2)
   unsigned off;  // byte offset of the pair's column inside a row
-  __device__ RecCol(const double *rec, int RP, int col)
-      : base(rec), row((size_t)kRecPlanes * RP), off(8u * (unsigned)rec_col_off(col, kRecPlanes)) {}
-  __device__ inline Rec at(int s) const {
-    const char *q = (const char *)(base + (size_t)s * row) + off;
+  int hmax;      // last valid row (prefetches beyond the data are clamped to it)
+  __device__ RecCol(const double *rec, int RP, int col, int M)
+      : base(rec), row((size_t)2 * kRecPlanes * RP), off(8u * (unsigned)rec_off(0, col, kRecPlanes, RP)), hmax((M - 1) >> 1) {}
+  // records of SNPs 2h and 2h + 1
+  __device__ inline void at2(int h, Rec &a, Rec &b) const {
+    const char *q = (const char *)(base + (size_t)h * row) + off;
+    const double2 t = *(const double2 *)q, r1 = *(const double2 *)(q + 1024), r2 = *(const double2 *)(q + 2048);
+    a.t = t.x; a.r1 = r1.x; a.r2 = r2.x;
+    b.t = t.y; b.r1 = r1.y; b.r2 = r2.y;
+  }
+  __device__ inline Rec at(int s) const {  // one record (tails)
+    const char *q = (const char *)(base + (size_t)(s >> 1) * row) + off + 8 * (s & 1);
     Rec r;
     r.t = *(const double *)q;
-    r.r1 = *(const double *)(q + 512);
-    r.r2 = *(const double *)(q + 1024);
+    r.r1 = *(const double *)(q + 1024);
+    r.r2 = *(const double *)(q + 2048);
     return r;
+  }
+  // kGroup records from SNP s (a multiple of 2); rows beyond the data are clamped (their values are never used)
+  __device__ inline void group(int s, Rec (&R)[4]) const {
+    const int h = s >> 1;
+    at2(min(h, hmax), R[0], R[1]);
+    at2(min(h + 1, hmax), R[2], R[3]);
   }
 };
 static constexpr double kLn2 = 0.6931471805599453094;
@@ -323,22 +337,17 @@ __device__ inline void fwd_group(const LaneC &C, const Rec (&R)[kGroup], double 
 template <int NBUF, class FG, class FT>
 __device__ inline void stream_records(const RecCol &col, int sb, int se, int M, FG &&on_group, FT &&on_tail) {
   constexpr int span = NBUF * kGroup;
-  int s = sb;
+  int s = sb;  // even: 0 or a chunk start
   Rec buf[NBUF][kGroup];
   if (s + span <= se) {
 #pragma unroll
-    for (int j = 0; j < NBUF; j++)
-#pragma unroll
-      for (int u = 0; u < kGroup; u++) buf[j][u] = col.at(s + j * kGroup + u);
+    for (int j = 0; j < NBUF; j++) col.group(s + j * kGroup, buf[j]);
   }
   for (; s + span <= se; s += span) {
 #pragma unroll
     for (int j = 0; j < NBUF; j++) {
       on_group(buf[j], s + j * kGroup);
-      // refill with the group one ring turn ahead; clamped to the last row of the matrix so that a prefetch past the
-      // end (discarded) stays a valid address
-#pragma unroll
-      for (int u = 0; u < kGroup; u++) buf[j][u] = col.at(min(s + span + j * kGroup + u, M - 1));
+      col.group(s + span + j * kGroup, buf[j]);  // the group one ring turn ahead
     }
   }
   for (; s < se; s++) on_tail(col.at(s), s);
@@ -465,7 +474,7 @@ like_kernel(const double *__restrict__ rec, int M, int RP, LaneMap lane_pair, Pa
   double x[1][3] = {{k0, k1, k2}};
   HalfNorm norm(k0, k1, k2, DR);
   const int lp = lane_pair(l);
-  like_forward<DR, NBUF>(RecCol(rec, RP, lp), 0, M, M, C, x, norm);
+  like_forward<DR, NBUF>(RecCol(rec, RP, lp, M), 0, M, M, C, x, norm);
   const double pr[3] = {x[0][0], x[0][1], x[0][2]};
   const int ex[3] = {norm.e0, norm.e1, norm.e2};
   long e;
@@ -479,20 +488,17 @@ template <int NBUF, class FG, class FT>
 __device__ inline void stream_records_rev(const RecCol &col, int sb, int se, FG &&on_group, FT &&on_tail) {
   constexpr int span = NBUF * kGroup;
   int s = se;  // rows [sb, s) are still to do
+  for (; (s & (kGroup - 1)) != 0 && s > sb; s--) on_tail(col.at(s - 1), s - 1);  // down to a group boundary
   Rec buf[NBUF][kGroup];
   if (s - span >= sb) {
 #pragma unroll
-    for (int j = 0; j < NBUF; j++)
-#pragma unroll
-      for (int u = 0; u < kGroup; u++) buf[j][u] = col.at(s - (j + 1) * kGroup + u);
+    for (int j = 0; j < NBUF; j++) col.group(s - (j + 1) * kGroup, buf[j]);
   }
   for (; s - span >= sb; s -= span) {
 #pragma unroll
     for (int j = 0; j < NBUF; j++) {
       on_group(buf[j], s - (j + 1) * kGroup);
-      // refill one ring turn further down; clamped to row 0 so that a prefetch below the range (discarded) stays valid
-#pragma unroll
-      for (int u = 0; u < kGroup; u++) buf[j][u] = col.at(max(s - span - (j + 1) * kGroup + u, 0));
+      col.group(max(s - span - (j + 1) * kGroup, 0), buf[j]);  // one ring turn further down; clamped to row 0
     }
   }
   for (s = s - 1; s >= sb; s--) on_tail(col.at(s), s);
@@ -522,7 +528,7 @@ like_halves_kernel(const double *__restrict__ rec, int M, int RP, LaneMap lane_p
   if (!lane_params(params, l, alim1, true, a, k2, k1, k0)) return;  // like_join_kernel rejects the lane
   LaneC C = make_lane(a, k2, k1, k0);
   const int mid = (M / 2) & ~(kGroup - 1);
-  const RecCol col(rec, RP, lane_pair(l));
+  const RecCol col(rec, RP, lane_pair(l), M);
   HalfNorm norm(k0, k1, k2, DR);
   if (!back) {
     double x[1][3] = {{k0, k1, k2}};
@@ -609,7 +615,7 @@ chunk_matrix_kernel(const double *__restrict__ rec, int M, int RP, LaneMap lane_
   double x[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
   int ex[3] = {0, 0, 0};
   const int lp = lane_pair(l);
-  sweep<3, DR, kNbufChunk>(RecCol(rec, RP, col0 + lp), sb, se, M, C, x, ex, [&](int tile) {
+  sweep<3, DR, kNbufChunk>(RecCol(rec, RP, col0 + lp, M), sb, se, M, C, x, ex, [&](int tile) {
     if (CKPT) {
       double *qm = ck.m(tile, lp);
       int *qe = ck.e(tile, lp);
@@ -850,12 +856,12 @@ decode_bwd_kernel(const double *__restrict__ rec, int M, int P, int RP, int col0
     a0 = astart[at]; a1 = astart[at + 1]; a2 = astart[at + 2];
     b0 = bend[at]; b1 = bend[at + 1]; b2 = bend[at + 2];
   }
-  const RecCol col(rec, RP, col0 + pc);
+  const RecCol col(rec, RP, col0 + pc, M);
   for (int tb = (se - 1) & ~(kTile - 1); tb >= sb; tb -= kTile) {
     int te = min(se, tb + kTile);
     Rec R[kTile];
 #pragma unroll
-    for (int u = 0; u < kTile; u++) R[u] = col.at(min(tb + u, te - 1));
+    for (int u = 0; u < kTile; u += 2) col.at2(min((tb + u) >> 1, col.hmax), R[u], R[u + 1]);
     ChunkProd X;
     {
       const double *qm = ck.m(tb / kTile, pc);
@@ -960,10 +966,10 @@ viterbi_kernel(const double *__restrict__ rec, int M, int P, int RP, const doubl
   double v0 = 0, v1 = 0, v2 = 0;
   bool started = false;
   for (int s = 0; s < M; s++) {
-    const double *row = rec + (size_t)s * kRecPlanesFull * RP + rec_col_off(p, kRecPlanesFull);
+    const double *row = rec + rec_off(s, p, kRecPlanesFull, RP);
     const double rt = row[0];
     if (__builtin_signbit(rt)) continue;
-    double l0 = log(row[64]), l1 = log(row[128]), l2 = log(row[192]);
+    double l0 = log(row[128]), l1 = log(row[256]), l2 = log(row[384]);
     if (!started) {
       double mx = fmax(log(k0), fmax(log(k1), log(k2)));
       v0 = mx + l0; v1 = mx + l1; v2 = mx + l2;
@@ -988,7 +994,7 @@ viterbi_kernel(const double *__restrict__ rec, int M, int P, int RP, const doubl
   int8_t *out = path + (size_t)p * M;
   int cur = started ? vwhich3(v0, v1, v2) : -1;
   for (int s = M - 1; s >= 0; s--) {
-    if (__builtin_signbit(rec[(size_t)s * kRecPlanesFull * RP + rec_col_off(p, kRecPlanesFull)])) { out[s] = -1; continue; }
+    if (__builtin_signbit(rec[rec_off(s, p, kRecPlanesFull, RP)])) { out[s] = -1; continue; }
     out[s] = (int8_t)cur;
     cur = (bp[(size_t)s * P + p] >> (2 * cur)) & 3;
   }

@@ -121,7 +121,7 @@ struct relate_hip_ctx {
   DBuf<int> dChoose;
   DBuf<uint8_t> dOrder;  // per-SNP preference order of the conditioning depths (windowed staging)
   // device: staged pair block
-  DBuf<double> dRec;            // kRecPlanes planes per SNP row (t, S1/S0, S2/S0), plane pitch recPitch
+  DBuf<double> dRec;            // staged records (t, S1/S0, S2/S0; layout: kernels_emis.hpp), padded pair count recPitch
   DBuf<double> dRecV;           // the full format (t, S0, S1, S2) of a block: Viterbi and inspection only
   DBuf<int32_t> dPairs;
   std::vector<int32_t> staged;  // pairs of the block currently in dRec (2 ints per pair)
@@ -267,7 +267,7 @@ int stage_block(relate_hip_t h, const int32_t *pairs, int P, bool full = false) 
   (full ? h->recPitchV : h->recPitch) = RP;
   const int words = 2, chunk = 64;  // SNPs per staging thread: 64 either way
   const int nruns = h->winMode ? (h->Wt + words - 1) / words : (h->M + chunk - 1) / chunk;
-  HIPCHK(h, R.ensure((size_t)h->M * (full ? kRecPlanesFull : kRecPlanes) * RP));
+  HIPCHK(h, R.ensure((size_t)((h->M + 1) / 2) * 2 * (full ? kRecPlanesFull : kRecPlanes) * RP));
   HIPCHK(h, h->dScM.ensure((size_t)nruns * RP));
   HIPCHK(h, h->dScE.ensure((size_t)nruns * RP));
   HIPCHK(h, h->dScN.ensure((size_t)nruns * RP));
@@ -418,12 +418,16 @@ int launch_like(relate_hip_t h, int nl, const LikeIO &io) {
         part = h->dCm.p;
       }
       dim3 grid((unsigned)(2 * (nlp / 256)));
-      if (dr)
-        hipLaunchKernelGGL((like_halves_kernel<true, 4>), grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch,
-                           io.map, io.params, nl, nlp, h->o.alim[1], part);
-      else
-        hipLaunchKernelGGL((like_halves_kernel<false, 4>), grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch,
-                           io.map, io.params, nl, nlp, h->o.alim[1], part);
+      static const int hn = [] { const char *e = getenv("RELATE_HALVES_NBUF"); return e ? atoi(e) : 4; }();
+#define LAUNCH_HALVES(DR, NB)                                                                                          \
+  hipLaunchKernelGGL((like_halves_kernel<DR, NB>), grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch, io.map, \
+                     io.params, nl, nlp, h->o.alim[1], part)
+      if (dr) LAUNCH_HALVES(true, 4);
+      else if (hn == 2) LAUNCH_HALVES(false, 2);
+      else if (hn == 3) LAUNCH_HALVES(false, 3);
+      else if (hn == 5) LAUNCH_HALVES(false, 5);
+      else LAUNCH_HALVES(false, 4);
+#undef LAUNCH_HALVES
       HIPCHK(h, hipGetLastError());
       hipLaunchKernelGGL(like_join_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, part, io.map, scale,
                          io.params, nl, nlp, h->o.alim[1], io.out);
@@ -1432,17 +1436,17 @@ int relate_hip_pair_emissions(relate_hip_t h, int ind1, int ind2, int *keep, dou
   int32_t pr[2] = {ind1, ind2};
   rc = stage_block(h, pr, 1, true);  // full format: t, S0, S1, S2 planes of one 64-pair group
   if (rc) return rc;
-  std::vector<double> r((size_t)h->M * kRecPlanesFull * h->recPitchV);
+  std::vector<double> r((size_t)((h->M + 1) / 2) * 2 * kRecPlanesFull * h->recPitchV);
   HIPCHK(h, hipMemcpy(r.data(), h->dRecV.p, sizeof(double) * r.size(), hipMemcpyDeviceToHost));
   for (int s = 0; s < h->M; s++) {
-    const double *q = &r[(size_t)s * kRecPlanesFull * h->recPitchV];  // pair 0 of group 0: planes 64 doubles apart
+    const double *q = &r[rec_off(s, 0, kRecPlanesFull, h->recPitchV)];  // planes 128 doubles apart
     bool k = !std::signbit(q[0]);  // dropped SNPs carry t = -0.0
     if (keep) keep[s] = k ? 1 : 0;
     if (t) t[s] = k ? q[0] : -1.0;
     if (S) {
-      S[s] = k ? q[64] : 0;
-      S[(size_t)h->M + s] = k ? q[128] : 0;
-      S[(size_t)2 * h->M + s] = k ? q[192] : 0;
+      S[s] = k ? q[128] : 0;
+      S[(size_t)h->M + s] = k ? q[256] : 0;
+      S[(size_t)2 * h->M + s] = k ? q[384] : 0;
     }
   }
   return RELATE_OK;
