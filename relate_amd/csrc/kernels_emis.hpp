@@ -242,8 +242,9 @@ __global__ void stage_pairs_kernel(const uint64_t *__restrict__ G, int M, int W,
                                    const double *__restrict__ mea, const double *__restrict__ pBA,
                                    const double *__restrict__ pbA, const double *__restrict__ pBa,
                                    const double *__restrict__ pba, int useLD, int back, int back2, double eps,
-                                   double *__restrict__ rec, int RP, double *__restrict__ sc_m, int *__restrict__ sc_e,
-                                   int *__restrict__ sc_n) {
+                                   double *__restrict__ rec, int RP, int col0, double *__restrict__ sc_m,
+                                   int *__restrict__ sc_e, int *__restrict__ sc_n) {
+  // pair p of the list goes to column col0 + p of the block
   long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   int nchunk = (M + chunk - 1) / chunk;
   if (tid >= (long)P * nchunk) return;
@@ -312,13 +313,13 @@ __global__ void stage_pairs_kernel(const uint64_t *__restrict__ G, int M, int W,
       last = s;
       if (run < back) run++;
     }
-    put_record<FULL>(rec, RP, s, p, state, t, e0, e1, e2, acc, nkept);
+    put_record<FULL>(rec, RP, s, col0 + p, state, t, e0, e1, e2, acc, nkept);
     if ((s & 7) == 7) acc.fold();
   }
   acc.fold();
-  sc_m[(size_t)c * RP + p] = acc.m;
-  sc_e[(size_t)c * RP + p] = acc.e;
-  sc_n[(size_t)c * RP + p] = nkept;
+  sc_m[(size_t)c * RP + col0 + p] = acc.m;
+  sc_e[(size_t)c * RP + col0 + p] = acc.e;
+  sc_n[(size_t)c * RP + col0 + p] = nkept;
 }
 
 // Folds the per-run partial products of the staging kernels in a fixed order: per pair the factor taken out of its
@@ -328,11 +329,15 @@ __global__ void stage_pairs_kernel(const uint64_t *__restrict__ G, int M, int W,
 static constexpr int kScaleSeg = 8;
 __global__ void __launch_bounds__(64 * kScaleSeg)
 scale_reduce_kernel(const double *__restrict__ sc_m, const int *__restrict__ sc_e, const int *__restrict__ sc_n,
-                    int nruns, int RP, int P, double *__restrict__ pm, int *__restrict__ pe, int *__restrict__ pn) {
+                    int nruns, int RP, int col0, int P, double *__restrict__ pm, int *__restrict__ pe,
+                    int *__restrict__ pn) {
+  // columns [col0, col0 + P) of the partial arrays and of the per-pair results
   __shared__ double lm[kScaleSeg][64];
   __shared__ int le[kScaleSeg][64], ln[kScaleSeg][64];
   const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
   const int p = blockIdx.x * 64 + lane;
+  sc_m += col0; sc_e += col0; sc_n += col0;
+  pm += col0; pe += col0; pn += col0;
   const int per = (nruns + kScaleSeg - 1) / kScaleSeg;
   const int c0 = seg * per, c1 = min(nruns, c0 + per);
   ScaleAcc acc;
@@ -452,8 +457,8 @@ stage_pairs_win_kernel(const uint64_t *__restrict__ Gt, int M, int Wt, const int
                        int words, const double *__restrict__ pos, const double *__restrict__ tab1,
                        const double *__restrict__ tabD, const double *__restrict__ mea,
                        const int *__restrict__ chooseG, const uint8_t *__restrict__ order, int useLD, int back,
-                       int back2, double *__restrict__ rec, int RP, double *__restrict__ sc_m, int *__restrict__ sc_e,
-                       int *__restrict__ sc_n) {
+                       int back2, double *__restrict__ rec, int RP, int col0, double *__restrict__ sc_m,
+                       int *__restrict__ sc_e, int *__restrict__ sc_n) {  // pair p of the list -> column col0 + p
   // Every plane store of a wave is 64 consecutive doubles: 512 B of whole lines per instruction.
   int bpc = (P + 255) / 256;
   int c = blockIdx.x / bpc;
@@ -560,7 +565,7 @@ stage_pairs_win_kernel(const uint64_t *__restrict__ Gt, int M, int Wt, const int
         double d = tpos[u] - lpos[u];
         make_record<FULL>(state[u], state[u] == 1 ? 0.0 : (d < 0 ? 10000000.0 : d), v[u][0], v[u][1], v[u][2], acc,
                           nkept, va);
-        double *q = rec + rec_off(w * 32 + k0 + u, p, NPL, RP);
+        double *q = rec + rec_off(w * 32 + k0 + u, col0 + p, NPL, RP);
         if (k0 + u + 1 < kmax) {  // uniform
           d = tpos[u + 1] - lpos[u + 1];
           make_record<FULL>(state[u + 1], state[u + 1] == 1 ? 0.0 : (d < 0 ? 10000000.0 : d), v[u + 1][0], v[u + 1][1],
@@ -578,9 +583,9 @@ stage_pairs_win_kernel(const uint64_t *__restrict__ Gt, int M, int Wt, const int
     b_lo = b_hi;
   }
   acc.fold();
-  sc_m[(size_t)c * RP + p] = acc.m;
-  sc_e[(size_t)c * RP + p] = acc.e;
-  sc_n[(size_t)c * RP + p] = nkept;
+  sc_m[(size_t)c * RP + col0 + p] = acc.m;
+  sc_e[(size_t)c * RP + col0 + p] = acc.e;
+  sc_n[(size_t)c * RP + col0 + p] = nkept;
 }
 
 }  // namespace relate

@@ -306,14 +306,25 @@ __device__ inline bool rec_dropped(const Rec &r) { return __builtin_signbit(r.t)
 // per group); a t whose high word equals the limit's counts as above it, which only ever picks the more careful tier.
 // NaN has the largest high word and goes to tier 2, where it propagates.
 template <int N, bool LOW = false>
-__device__ inline int group_tier(const LaneC &C, const Rec (&R)[N]) {
+__device__ inline int group_tier_h(int hlim0, int hlim1, int hlimm, const Rec (&R)[N]) {
   int hmax = hi_word(R[0].t);
 #pragma unroll
   for (int u = 1; u < N; u++) hmax = max(hmax, hi_word(R[u].t));
-  if (__builtin_amdgcn_ballot_w64(!(hmax < C.hlim0)) == 0)
-    return (LOW && __builtin_amdgcn_ballot_w64(!(hmax < C.hlimm)) == 0) ? -1 : 0;
-  if (__builtin_amdgcn_ballot_w64(!(hmax < C.hlim1)) == 0) return 1;
+  if (__builtin_amdgcn_ballot_w64(!(hmax < hlim0)) == 0)
+    return (LOW && __builtin_amdgcn_ballot_w64(!(hmax < hlimm)) == 0) ? -1 : 0;
+  if (__builtin_amdgcn_ballot_w64(!(hmax < hlim1)) == 0) return 1;
   return 2;
+}
+template <int N, bool LOW = false>
+__device__ inline int group_tier(const LaneC &C, const Rec (&R)[N]) {
+  return group_tier_h<N, LOW>(C.hlim0, C.hlim1, C.hlimm, R);
+}
+
+// one vector of one parameter point through one record (the NV = 1 case of fwd_step on a plain array)
+template <bool DR, int TIER>
+__device__ inline void fwd_step1(const LaneC &C, const Rec &r, double (&x)[3]) {
+  double (&xv)[1][3] = *reinterpret_cast<double (*)[1][3]>(&x);
+  fwd_step<1, DR, TIER>(C, r, xv);
 }
 
 template <int NV, bool DR, int TIER>
@@ -403,6 +414,7 @@ struct HalfNorm {
   double z0, z1, z2;  // 0 for a state with k_x == 0
   bool iso;           // k1 == 0: independent components
   int e0 = 0, e1 = 0, e2 = 0;
+  __device__ HalfNorm() : z0(1), z1(1), z2(1), iso(false) {}
   __device__ HalfNorm(double k0, double k1, double k2, bool dr)  // the double-recombination T mixes 0 and 2 whatever k1 is
       : z0(k0 == 0 ? 0.0 : 1.0), z1(k1 == 0 ? 0.0 : 1.0), z2(k2 == 0 ? 0.0 : 1.0), iso(!dr && k1 == 0) {}
   __device__ inline void operator()(double &x0, double &x1, double &x2) {
@@ -441,45 +453,100 @@ __device__ inline double combine3(const double (&pr)[3], const int (&ex)[3], lon
   return __builtin_amdgcn_ldexp(tot, -fe);
 }
 
-// forward half of a likelihood sweep: rows [sb, se) from x, exponents in norm
-template <bool DR, int NBUF>
-__device__ inline void like_forward(const RecCol &col, int sb, int se, int M, const LaneC &C, double (&x)[1][3],
-                                    HalfNorm &norm) {
+// A lane of the likelihood sweeps carries NV parameter points of ONE pair: the record ring, its loads, the tier test
+// and the loop are shared by NV independent chains (the optimiser asks for 3-7 points of a pair at a time, and several
+// restarts of a pair run side by side).  Per point-step that is 1.5 / NV vector loads and 1 / NV of the loop overhead,
+// and NV chains interleave in the VALU.  Slots: lane l owns points [l NV, l NV + NV) of the launch (the host pads a
+// pair's points to a multiple of NV with copies); a rejected point rides along on harmless parameters.
+template <int NV>
+struct LaneSet {
+  LaneC C[NV];
+  HalfNorm norm[NV];
+  bool ok[NV];
+  int hl0, hl1, hlm;  // tier limits: the most careful of the lane's points
+  bool any;
+  __device__ inline void init(const double *__restrict__ params, int slot0, int nslots, double alim1, bool dr,
+                              double (&x)[NV][3]) {
+    hl0 = hl1 = hlm = 2147483647;
+    any = false;
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      double a, k2, k1, k0;
+      ok[v] = lane_params(params, min(slot0 + v, nslots - 1), alim1, true, a, k2, k1, k0);
+      any |= ok[v];
+      if (!ok[v]) { a = 0.01; k2 = 0; k1 = 0; k0 = 1; }
+      C[v] = make_lane(a, k2, k1, k0);
+      norm[v] = HalfNorm(k0, k1, k2, dr);
+      x[v][0] = k0; x[v][1] = k1; x[v][2] = k2;
+      hl0 = min(hl0, C[v].hlim0); hl1 = min(hl1, C[v].hlim1); hlm = min(hlm, C[v].hlimm);
+    }
+  }
+};
+
+template <int NV, bool DR, int TIER>
+__device__ inline void fwd_group_mp(const LaneSet<NV> &L, const Rec (&R)[kGroup], double (&x)[NV][3]) {
+#pragma unroll
+  for (int u = 0; u < kGroup; u++)
+#pragma unroll
+    for (int v = 0; v < NV; v++) fwd_step1<DR, TIER>(L.C[v], R[u], x[v]);
+}
+template <int NV, bool DR, int TIER>
+__device__ inline void bwd_group_mp(const LaneSet<NV> &L, const Rec (&R)[kGroup], double (&b)[NV][3]) {
+#pragma unroll
+  for (int u = kGroup - 1; u >= 0; u--)
+#pragma unroll
+    for (int v = 0; v < NV; v++) bwd_step<DR, TIER>(L.C[v], R[u], b[v][0], b[v][1], b[v][2]);
+}
+
+// forward half of a likelihood sweep: rows [sb, se) from x, exponents in L.norm
+template <bool DR, int NBUF, int NV>
+__device__ inline void like_forward(const RecCol &col, int sb, int se, int M, LaneSet<NV> &L, double (&x)[NV][3]) {
+  auto renorm = [&]() {
+#pragma unroll
+    for (int v = 0; v < NV; v++) L.norm[v](x[v][0], x[v][1], x[v][2]);
+  };
   stream_records<NBUF>(
       col, sb, se, M,
       [&](const Rec(&R)[kGroup], int s) {
-        fwd_group<1, DR>(C, R, x);
-        if ((s & 12) == 12) norm(x[0][0], x[0][1], x[0][2]);  // every fourth group: 16 steps between renormalisations
+        int tier = group_tier_h<kGroup, !DR>(L.hl0, L.hl1, L.hlm, R);
+        if (tier < 0) fwd_group_mp<NV, DR, -1>(L, R, x);
+        else if (tier == 0) fwd_group_mp<NV, DR, 0>(L, R, x);
+        else if (tier == 1) fwd_group_mp<NV, DR, 1>(L, R, x);
+        else fwd_group_mp<NV, DR, 2>(L, R, x);
+        if ((s & 12) == 12) renorm();  // every fourth group: 16 steps between renormalisations
       },
       [&](const Rec &r, int s) {
-        fwd_step<1, DR, 2>(C, r, x);
-        if ((s & 7) == 7) norm(x[0][0], x[0][1], x[0][2]);  // the tail can be NBUF * kGroup - 1 records long
+#pragma unroll
+        for (int v = 0; v < NV; v++) fwd_step1<DR, 2>(L.C[v], r, x[v]);
+        if ((s & 7) == 7) renorm();  // the tail can be NBUF * kGroup - 1 records long
       });
-  norm(x[0][0], x[0][1], x[0][2]);
+  renorm();
 }
 
-// K5, one sweep.  out[l] = -log-likelihood, SYS_MAX for a rejected point, NaN/inf if the recursion broke down.
+// K5, one sweep.  out[slot] = -log-likelihood, SYS_MAX for a rejected point, NaN/inf if the recursion broke down.
 // NBUF = record groups in flight per lane, chosen by the host from the waves per SIMD the launch can fill: a lane is
-// one serial chain, so with one wave per SIMD only the depth of its own prefetch hides HBM latency; with two waves
-// NBUF 4; from three waves on NBUF 2, where a deeper ring would cost the third wave.
-template <bool DR, int NBUF>
+// a serial chain per point, so with one wave per SIMD only the depth of its own prefetch hides HBM latency; with two
+// waves NBUF 4; from three waves on NBUF 2, where a deeper ring would cost the third wave.
+template <bool DR, int NBUF, int NV>
 __global__ void __launch_bounds__(256)
 like_kernel(const double *__restrict__ rec, int M, int RP, LaneMap lane_pair, PairScale scale,
-            const double *__restrict__ params, int nlanes, double alim1, double *__restrict__ out) {
-  int l = blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= nlanes) return;
-  double a, k2, k1, k0;
-  if (!lane_params(params, l, alim1, true, a, k2, k1, k0)) { out[l] = 10000000.0; return; }
-  LaneC C = make_lane(a, k2, k1, k0);
-  double x[1][3] = {{k0, k1, k2}};
-  HalfNorm norm(k0, k1, k2, DR);
-  const int lp = lane_pair(l);
-  like_forward<DR, NBUF>(RecCol(rec, RP, lp, M), 0, M, M, C, x, norm);
-  const double pr[3] = {x[0][0], x[0][1], x[0][2]};
-  const int ex[3] = {norm.e0, norm.e1, norm.e2};
-  long e;
-  double tot = combine3(pr, ex, e);
-  out[l] = neg_loglik(tot, e, scale, lp);
+            const double *__restrict__ params, int nslots, double alim1, double *__restrict__ out) {
+  const int slot0 = (blockIdx.x * blockDim.x + threadIdx.x) * NV;
+  if (slot0 >= nslots) return;
+  LaneSet<NV> L;
+  double x[NV][3];
+  L.init(params, slot0, nslots, alim1, DR, x);
+  const int lp = lane_pair(slot0);
+  if (L.any) like_forward<DR, NBUF, NV>(RecCol(rec, RP, lp, M), 0, M, M, L, x);
+#pragma unroll
+  for (int v = 0; v < NV; v++) {
+    if (slot0 + v >= nslots) break;
+    const double pr[3] = {x[v][0], x[v][1], x[v][2]};
+    const int ex[3] = {L.norm[v].e0, L.norm[v].e1, L.norm[v].e2};
+    long e;
+    double tot = combine3(pr, ex, e);
+    out[slot0 + v] = L.ok[v] ? neg_loglik(tot, e, scale, lp) : 10000000.0;
+  }
 }
 
 // The same records from the last row down (the backward half of the two-sided likelihood): groups of kGroup rows
@@ -516,43 +583,53 @@ __device__ inline void bwd_group_t(const LaneC &C, const Rec (&R)[kGroup], doubl
 // up to one wave per SIMD (a serial chain per lane, 62 % of the issue rate) becomes one of up to two.
 // part: 12 x nlp doubles (alpha[3], its three exponents, beta[3], its three exponents), nlp = lanes padded to 256.
 //
-template <bool DR, int NBUF>
+template <bool DR, int NBUF, int NV>
 __global__ void __launch_bounds__(256)
 like_halves_kernel(const double *__restrict__ rec, int M, int RP, LaneMap lane_pair,
-                   const double *__restrict__ params, int nlanes, int nlp, double alim1, double *__restrict__ part) {
-  const int nb = nlp / 256;
+                   const double *__restrict__ params, int nslots, int nsp, double alim1, double *__restrict__ part) {
+  // nsp = slots padded to 256 NV: workgroups [0, nb) forward, [nb, 2 nb) backward; part is indexed by slot
+  const int nb = nsp / (256 * NV);
   const bool back = (int)blockIdx.x >= nb;
-  int l = ((int)blockIdx.x - (back ? nb : 0)) * 256 + threadIdx.x;
-  if (l >= nlanes) return;
-  double a, k2, k1, k0;
-  if (!lane_params(params, l, alim1, true, a, k2, k1, k0)) return;  // like_join_kernel rejects the lane
-  LaneC C = make_lane(a, k2, k1, k0);
+  const int slot0 = (((int)blockIdx.x - (back ? nb : 0)) * 256 + threadIdx.x) * NV;
+  if (slot0 >= nslots) return;
+  LaneSet<NV> L;
+  double x[NV][3];
+  L.init(params, slot0, nslots, alim1, DR, x);
+  if (!L.any) return;  // like_join_kernel rejects the points
   const int mid = (M / 2) & ~(kGroup - 1);
-  const RecCol col(rec, RP, lane_pair(l), M);
-  HalfNorm norm(k0, k1, k2, DR);
+  const RecCol col(rec, RP, lane_pair(slot0), M);
   if (!back) {
-    double x[1][3] = {{k0, k1, k2}};
-    like_forward<DR, NBUF>(col, 0, mid, M, C, x, norm);
-    norm.store(part + l, (size_t)nlp, x[0][0], x[0][1], x[0][2]);
+    like_forward<DR, NBUF, NV>(col, 0, mid, M, L, x);
+#pragma unroll
+    for (int v = 0; v < NV; v++)
+      if (slot0 + v < nslots) L.norm[v].store(part + slot0 + v, (size_t)nsp, x[v][0], x[v][1], x[v][2]);
     return;
   }
-  double b0 = 1, b1 = 1, b2 = 1;
+#pragma unroll
+  for (int v = 0; v < NV; v++) { x[v][0] = 1; x[v][1] = 1; x[v][2] = 1; }
+  auto renorm = [&]() {
+#pragma unroll
+    for (int v = 0; v < NV; v++) L.norm[v](x[v][0], x[v][1], x[v][2]);
+  };
   stream_records_rev<NBUF>(
       col, mid, M,
       [&](const Rec(&R)[kGroup], int s) {
-        int tier = group_tier<kGroup, !DR>(C, R);
-        if (tier < 0) bwd_group_t<DR, -1>(C, R, b0, b1, b2);
-        else if (tier == 0) bwd_group_t<DR, 0>(C, R, b0, b1, b2);
-        else if (tier == 1) bwd_group_t<DR, 1>(C, R, b0, b1, b2);
-        else bwd_group_t<DR, 2>(C, R, b0, b1, b2);
-        if ((s & 12) == 0) norm(b0, b1, b2);
+        int tier = group_tier_h<kGroup, !DR>(L.hl0, L.hl1, L.hlm, R);
+        if (tier < 0) bwd_group_mp<NV, DR, -1>(L, R, x);
+        else if (tier == 0) bwd_group_mp<NV, DR, 0>(L, R, x);
+        else if (tier == 1) bwd_group_mp<NV, DR, 1>(L, R, x);
+        else bwd_group_mp<NV, DR, 2>(L, R, x);
+        if ((s & 12) == 0) renorm();
       },
       [&](const Rec &r, int s) {
-        bwd_step<DR, 2>(C, r, b0, b1, b2);
-        if ((s & 7) == 0) norm(b0, b1, b2);
+#pragma unroll
+        for (int v = 0; v < NV; v++) bwd_step<DR, 2>(L.C[v], r, x[v][0], x[v][1], x[v][2]);
+        if ((s & 7) == 0) renorm();
       });
-  norm(b0, b1, b2);
-  norm.store(part + (size_t)6 * nlp + l, (size_t)nlp, b0, b1, b2);
+  renorm();
+#pragma unroll
+  for (int v = 0; v < NV; v++)
+    if (slot0 + v < nslots) L.norm[v].store(part + (size_t)6 * nsp + slot0 + v, (size_t)nsp, x[v][0], x[v][1], x[v][2]);
 }
 
 __global__ void __launch_bounds__(256)
@@ -690,27 +767,34 @@ like_combine_kernel(ChunkOut O, LaneMap lane_pair, PairScale scale, const double
   double f0 = k0, f1 = k1, f2 = k2;
   long esum = 0;
   double tot;
-  ChunkProd X = load_chunk(O, n, (size_t)l);
-  if (!double_recom && k1 == 0) {
-    int e0 = 0, e2 = 0;
-    for (int c = 0; c < nchunk; c++) {
-      ChunkProd Xn = load_chunk(O, n, (size_t)min(c + 1, nchunk - 1) * nlp + l);
-      f0 *= X.m[0]; f2 *= X.m[8];
-      int g0 = f0 > 0 ? __builtin_amdgcn_frexp_exp(f0) : 0, g2 = f2 > 0 ? __builtin_amdgcn_frexp_exp(f2) : 0;
-      f0 = __builtin_amdgcn_ldexp(f0, -g0); f2 = __builtin_amdgcn_ldexp(f2, -g2);
-      e0 += X.e[0] + g0; e2 += X.e[2] + g2;
-      X = Xn;
+  // the fold is serial per lane and its loads are strided: kAhead products are fetched at a time (one round trip per
+  // batch instead of one per chunk -- a launch of a few hundred lanes has up to ~1 000 chunks)
+  constexpr int kAhead = 8;
+  const bool iso = !double_recom && k1 == 0;
+  int e0 = 0, e2 = 0;
+  for (int cb = 0; cb < nchunk; cb += kAhead) {
+    ChunkProd X[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; u++) X[u] = load_chunk(O, n, (size_t)min(cb + u, nchunk - 1) * nlp + l);
+#pragma unroll
+    for (int u = 0; u < kAhead; u++) {
+      if (cb + u >= nchunk) break;
+      if (iso) {
+        f0 *= X[u].m[0]; f2 *= X[u].m[8];
+        int g0 = f0 > 0 ? __builtin_amdgcn_frexp_exp(f0) : 0, g2 = f2 > 0 ? __builtin_amdgcn_frexp_exp(f2) : 0;
+        f0 = __builtin_amdgcn_ldexp(f0, -g0); f2 = __builtin_amdgcn_ldexp(f2, -g2);
+        e0 += X[u].e[0] + g0; e2 += X[u].e[2] + g2;
+      } else {
+        esum += apply_chunk_fwd(f0, f1, f2, X[u]);
+        esum += rescale3(f0, f1, f2);
+      }
     }
+  }
+  if (iso) {
     const double pr[3] = {f0, 0.0, f2};
     const int ex[3] = {e0, 0, e2};
     tot = combine3(pr, ex, esum);
   } else {
-    for (int c = 0; c < nchunk; c++) {
-      ChunkProd Xn = load_chunk(O, n, (size_t)min(c + 1, nchunk - 1) * nlp + l);
-      esum += apply_chunk_fwd(f0, f1, f2, X);
-      esum += rescale3(f0, f1, f2);
-      X = Xn;
-    }
     tot = (f0 + f1) + f2;
   }
   out[l] = neg_loglik(tot, esum, scale, lane_pair(l));

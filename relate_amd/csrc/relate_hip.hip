@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <initializer_list>
 #include <map>
 #include <mutex>
@@ -62,6 +63,7 @@ struct LaneBufs {
   size_t cap = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr, done = nullptr;
   int nl = 0, chunks = 1;
+  int nv = 1;  // points per lane the slot layout of this launch allows (pick_nv)
   hipError_t ensure(size_t n) {
     if (!e0) {
       hipError_t e = hipEventCreate(&e0);
@@ -248,6 +250,56 @@ inline MemNeed need_path(relate_hip_t h, bool want) {
   return {want ? kRecFullBytes : 0.0, h->dRecV.cap * sizeof(double) + h->dBp.cap + h->dPath.cap};
 }
 
+// K4: n pairs into columns [col0, col0 + n) of a record buffer whose padded pair count is RP (full: dRecV, else dRec
+// together with its per-pair factors and kept-SNP counts).  Returns with the work done and the counts on the host.
+int stage_cols(relate_hip_t h, const int32_t *pairs, int n, int col0, int RP, bool full) {
+  for (int p = 0; p < n; p++) {
+    int a = pairs[2 * p], b = pairs[2 * p + 1];
+    if (a < 0 || a >= h->N || b < 0 || b >= h->N)
+      return fail(h, RELATE_E_ARG, "pair index out of range (the data set has " + std::to_string(h->N) + " individuals)");
+  }
+  DBuf<double> &R = full ? h->dRecV : h->dRec;
+  const int words = 2, chunk = 64;  // SNPs per staging thread: 64 either way
+  const int nruns = h->winMode ? (h->Wt + words - 1) / words : (h->M + chunk - 1) / chunk;
+  HIPCHK(h, h->dPairs.ensure((size_t)2 * n));
+  HIPCHK(h, hipMemcpyAsync(h->dPairs.p, pairs, sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  if (h->winMode) {
+    unsigned grid = (unsigned)((size_t)nruns * ((n + 255) / 256));
+#define STAGE_WIN(FULL)                                                                                              \
+  hipLaunchKernelGGL(stage_pairs_win_kernel<FULL>, dim3(grid), dim3(256), 0, h->stream, h->dGt.p, h->M, h->Wt,         \
+                     h->dPairs.p, n, words, h->dPos.p, h->dTab1.p, h->dTabD.p, h->dMea.p, h->dChoose.p, h->dOrder.p, \
+                     h->useLD, h->o.back, h->back2, R.p, RP, col0, h->dScM.p, h->dScE.p, h->dScN.p)
+    if (full) STAGE_WIN(true);
+    else STAGE_WIN(false);
+#undef STAGE_WIN
+  } else {
+    long nthreads = (long)n * nruns;
+#define STAGE_GEN(FULL)                                                                                               \
+  hipLaunchKernelGGL(stage_pairs_kernel<FULL>, dim3(blocks_for(nthreads, 256)), dim3(256), 0, h->stream, h->dG.p, h->M, \
+                     h->W, h->dPairs.p, n, chunk, h->dPos.p, h->dTab1.p, h->dTabL.p, h->dChoose.p, h->dMea.p,         \
+                     h->dPBA.p, h->dPbA.p, h->dPBa.p, h->dPba.p, h->useLD, h->o.back, h->back2, h->o.epsilon, R.p,    \
+                     RP, col0, h->dScM.p, h->dScE.p, h->dScN.p)
+    if (full) STAGE_GEN(true);
+    else STAGE_GEN(false);
+#undef STAGE_GEN
+  }
+  HIPCHK(h, hipGetLastError());
+  if (!full) {
+    hipLaunchKernelGGL(scale_reduce_kernel, dim3(blocks_for(n, 64)), dim3(64 * kScaleSeg), 0, h->stream, h->dScM.p,
+                       h->dScE.p, h->dScN.p, nruns, RP, col0, n, h->dPairM.p, h->dPairE.p, h->dNsnp.p);
+    HIPCHK(h, hipGetLastError());
+  }
+  HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+  if (!full)
+    HIPCHK(h, hipMemcpyAsync(h->h_nsnp.data() + col0, h->dNsnp.p + col0, sizeof(int) * n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  float ms = 0;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+  h->timings[0] = ms;
+  return 0;
+}
+
 // K4 for a block of pairs (skipped when the same block is already staged).  full: the four-plane format into dRecV
 // (Viterbi, inspection); the block in dRec and its per-pair factors stay as they are.
 int stage_block(relate_hip_t h, const int32_t *pairs, int P, bool full = false) {
@@ -256,62 +308,23 @@ int stage_block(relate_hip_t h, const int32_t *pairs, int P, bool full = false) 
     h->timings[0] = 0;
     return 0;
   }
-  for (int p = 0; p < P; p++) {
-    int a = pairs[2 * p], b = pairs[2 * p + 1];
-    if (a < 0 || a >= h->N || b < 0 || b >= h->N)
-      return fail(h, RELATE_E_ARG, "pair index out of range (the data set has " + std::to_string(h->N) + " individuals)");
-  }
   memo.clear();
   const int RP = rec_pitch(P);
   DBuf<double> &R = full ? h->dRecV : h->dRec;
   (full ? h->recPitchV : h->recPitch) = RP;
-  const int words = 2, chunk = 64;  // SNPs per staging thread: 64 either way
-  const int nruns = h->winMode ? (h->Wt + words - 1) / words : (h->M + chunk - 1) / chunk;
+  const int nruns = h->winMode ? (h->Wt + 1) / 2 : (h->M + 63) / 64;
   HIPCHK(h, R.ensure((size_t)((h->M + 1) / 2) * 2 * (full ? kRecPlanesFull : kRecPlanes) * RP));
   HIPCHK(h, h->dScM.ensure((size_t)nruns * RP));
   HIPCHK(h, h->dScE.ensure((size_t)nruns * RP));
   HIPCHK(h, h->dScN.ensure((size_t)nruns * RP));
-  HIPCHK(h, h->dPairs.ensure((size_t)2 * P));
-  HIPCHK(h, hipMemcpyAsync(h->dPairs.p, pairs, sizeof(int32_t) * 2 * P, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-  if (h->winMode) {
-    unsigned grid = (unsigned)((size_t)nruns * ((P + 255) / 256));
-#define STAGE_WIN(FULL)                                                                                              \
-  hipLaunchKernelGGL(stage_pairs_win_kernel<FULL>, dim3(grid), dim3(256), 0, h->stream, h->dGt.p, h->M, h->Wt,         \
-                     h->dPairs.p, P, words, h->dPos.p, h->dTab1.p, h->dTabD.p, h->dMea.p, h->dChoose.p, h->dOrder.p, \
-                     h->useLD, h->o.back, h->back2, R.p, RP, h->dScM.p, h->dScE.p, h->dScN.p)
-    if (full) STAGE_WIN(true);
-    else STAGE_WIN(false);
-#undef STAGE_WIN
-  } else {
-    long nthreads = (long)P * nruns;
-#define STAGE_GEN(FULL)                                                                                               \
-  hipLaunchKernelGGL(stage_pairs_kernel<FULL>, dim3(blocks_for(nthreads, 256)), dim3(256), 0, h->stream, h->dG.p, h->M, \
-                     h->W, h->dPairs.p, P, chunk, h->dPos.p, h->dTab1.p, h->dTabL.p, h->dChoose.p, h->dMea.p,         \
-                     h->dPBA.p, h->dPbA.p, h->dPBa.p, h->dPba.p, h->useLD, h->o.back, h->back2, h->o.epsilon, R.p,    \
-                     RP, h->dScM.p, h->dScE.p, h->dScN.p)
-    if (full) STAGE_GEN(true);
-    else STAGE_GEN(false);
-#undef STAGE_GEN
-  }
-  HIPCHK(h, hipGetLastError());
   if (!full) {
-    HIPCHK(h, h->dPairM.ensure(P));
-    HIPCHK(h, h->dPairE.ensure(P));
-    HIPCHK(h, h->dNsnp.ensure(P));
-    hipLaunchKernelGGL(scale_reduce_kernel, dim3(blocks_for(P, 64)), dim3(64 * kScaleSeg), 0, h->stream, h->dScM.p, h->dScE.p,
-                       h->dScN.p, nruns, RP, P, h->dPairM.p, h->dPairE.p, h->dNsnp.p);
-    HIPCHK(h, hipGetLastError());
-  }
-  HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-  if (!full) {
+    HIPCHK(h, h->dPairM.ensure(RP));
+    HIPCHK(h, h->dPairE.ensure(RP));
+    HIPCHK(h, h->dNsnp.ensure(RP));
     h->h_nsnp.resize(P);
-    HIPCHK(h, hipMemcpyAsync(h->h_nsnp.data(), h->dNsnp.p, sizeof(int) * P, hipMemcpyDeviceToHost, h->stream));
   }
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  float ms = 0;
-  HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
-  h->timings[0] = ms;
+  int rc = stage_cols(h, pairs, P, 0, RP, full);
+  if (rc) return rc;
   memo.assign(pairs, pairs + 2 * P);
   return 0;
 }
@@ -384,7 +397,23 @@ struct LikeIO {
   double *out;           // device, 1 per lane
   unsigned char *fixed;  // nullptr: the handle's grow-only buffers (may allocate); else a scratch of fixed_bytes
   size_t fixed_bytes;
+  int nv = 1;            // every run of nv consecutive slots (from a multiple of nv) belongs to one pair: a lane may carry them
 };
+
+// Points per lane for a launch of `slots` points whose layout allows up to nv_max (kernels_hmm.hpp, LaneSet).  Two
+// chains per lane pay once the lanes still fill the SIMDs: measured at M = 5e5 (10 000 pairs), 60 000 points run at 701 G
+// point-steps/s one per lane (two-sided, 1.8 waves per SIMD) and 706 G two per lane; 120 000 points at 799 G against
+// 874 G; 240 000 points at 870 G against 986 G (92 % of what a pure FMA stream sustains on this part).  Three per lane
+// need more than 256 VGPRs.  RELATE_LIKE_NV overrides (tuning, tests).
+constexpr long kTwoPerLaneFrom = 98304;
+int pick_nv(long slots, int nv_max) {
+  static const int forced = [] { const char *e = getenv("RELATE_LIKE_NV"); return e ? atoi(e) : 0; }();
+  int nv = forced > 0 ? forced : (slots > kTwoPerLaneFrom ? 2 : 1);
+  if (nv > nv_max) nv = nv_max;
+  if (nv > 2) nv = 2;
+  if (nv < 1) nv = 1;
+  return nv;
+}
 
 // K5 launches for nl lanes of the staged block
 int launch_like(relate_hip_t h, int nl, const LikeIO &io) {
@@ -406,48 +435,63 @@ int launch_like(relate_hip_t h, int nl, const LikeIO &io) {
   const bool dr = h->o.double_recom != 0;
   const PairScale scale{h->dPairM.p, h->dPairE.p};
   if (nchunk == 1) {
+    const int NV = io.nv;
+    const long lanes = (nl + NV - 1) / NV;
+    const int nsp = (nl + 256 * NV - 1) / (256 * NV) * (256 * NV);  // slots padded to whole workgroups
     // ring depth by the waves per SIMD this launch can fill (kernels_hmm.hpp, like_kernel)
     const long simd_lanes = 256L * 4 * 64;
     // Up to one wave per SIMD: the two-sided sweep instead (twice the lanes, half the length, like_halves_kernel).
     // RELATE_LIKE_TWO_SIDED=0 keeps the single sweep (tests, tuning).
     static const bool two_sided = [] { const char *e = getenv("RELATE_LIKE_TWO_SIDED"); return !(e && atoi(e) == 0); }();
-    if (two_sided && nl <= simd_lanes && h->M >= 64 && (!io.fixed || (size_t)12 * nlp * sizeof(double) <= io.fixed_bytes)) {
+    // One point per lane: up to 1.5 turns of lanes (three waves per SIMD of half lanes: the shallow-ring build holds
+    // three, 148 VGPRs); a plain sweep of 1.0-1.5 waves per SIMD would cost what two full waves cost.
+    const long two_sided_max = NV == 1 ? simd_lanes * 3 / 2 : simd_lanes;
+    if (two_sided && lanes <= two_sided_max && h->M >= 64 && (!io.fixed || (size_t)12 * nsp * sizeof(double) <= io.fixed_bytes)) {
       double *part = reinterpret_cast<double *>(io.fixed);
       if (!io.fixed) {
-        HIPCHK(h, h->dCm.ensure((size_t)12 * nlp));
+        HIPCHK(h, h->dCm.ensure((size_t)12 * nsp));
         part = h->dCm.p;
       }
-      dim3 grid((unsigned)(2 * (nlp / 256)));
-      static const int hn = [] { const char *e = getenv("RELATE_HALVES_NBUF"); return e ? atoi(e) : 4; }();
-#define LAUNCH_HALVES(DR, NB)                                                                                          \
-  hipLaunchKernelGGL((like_halves_kernel<DR, NB>), grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch, io.map, \
-                     io.params, nl, nlp, h->o.alim[1], part)
-      if (dr) LAUNCH_HALVES(true, 4);
-      else if (hn == 2) LAUNCH_HALVES(false, 2);
-      else if (hn == 3) LAUNCH_HALVES(false, 3);
-      else if (hn == 5) LAUNCH_HALVES(false, 5);
-      else LAUNCH_HALVES(false, 4);
+      dim3 grid((unsigned)(2 * (nsp / (256 * NV))));
+      const bool shallow = lanes > simd_lanes;
+#define LAUNCH_HALVES(DR, NB, NVV)                                                                                     \
+  hipLaunchKernelGGL((like_halves_kernel<DR, NB, NVV>), grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch,   \
+                     io.map, io.params, nl, nsp, h->o.alim[1], part)
+      if (dr) {
+        if (NV == 2) LAUNCH_HALVES(true, 4, 2);
+        else if (shallow) LAUNCH_HALVES(true, 2, 1);
+        else LAUNCH_HALVES(true, 4, 1);
+      } else {
+        if (NV == 2) LAUNCH_HALVES(false, 4, 2);
+        else if (shallow) LAUNCH_HALVES(false, 2, 1);
+        else LAUNCH_HALVES(false, 4, 1);
+      }
 #undef LAUNCH_HALVES
       HIPCHK(h, hipGetLastError());
       hipLaunchKernelGGL(like_join_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, part, io.map, scale,
-                         io.params, nl, nlp, h->o.alim[1], io.out);
+                         io.params, nl, nsp, h->o.alim[1], io.out);
       HIPCHK(h, hipGetLastError());
       return 0;
     }
-    const int nbuf = nl <= simd_lanes ? 6 : (nl <= 2 * simd_lanes ? 4 : 2);
-    dim3 grid(blocks_for(nl, 256)), block(256);
-#define LAUNCH_LIKE(DR, NB)                                                                                   \
-  hipLaunchKernelGGL((like_kernel<DR, NB>), grid, block, 0, h->stream, h->dRec.p, h->M, h->recPitch, io.map, \
+    const int nbuf = lanes <= simd_lanes ? 6 : (lanes <= 2 * simd_lanes ? 4 : 2);
+    dim3 grid(blocks_for(lanes, 256)), block(256);
+#define LAUNCH_LIKE(DR, NB, NVV)                                                                                   \
+  hipLaunchKernelGGL((like_kernel<DR, NB, NVV>), grid, block, 0, h->stream, h->dRec.p, h->M, h->recPitch, io.map, \
                      scale, io.params, nl, h->o.alim[1], io.out)
-    if (dr) {
-      if (nbuf == 6) LAUNCH_LIKE(true, 6);
-      else if (nbuf == 4) LAUNCH_LIKE(true, 4);
-      else LAUNCH_LIKE(true, 2);
-    } else {
-      if (nbuf == 6) LAUNCH_LIKE(false, 6);
-      else if (nbuf == 4) LAUNCH_LIKE(false, 4);
-      else LAUNCH_LIKE(false, 2);
-    }
+#define LAUNCH_LIKE_NV(DR)                                      \
+  do {                                                          \
+    if (NV == 2) {                                              \
+      if (nbuf == 2) LAUNCH_LIKE(DR, 2, 2);                     \
+      else LAUNCH_LIKE(DR, 4, 2);                               \
+    } else {                                                    \
+      if (nbuf == 6) LAUNCH_LIKE(DR, 6, 1);                     \
+      else if (nbuf == 4) LAUNCH_LIKE(DR, 4, 1);                \
+      else LAUNCH_LIKE(DR, 2, 1);                               \
+    }                                                           \
+  } while (0)
+    if (dr) LAUNCH_LIKE_NV(true);
+    else LAUNCH_LIKE_NV(false);
+#undef LAUNCH_LIKE_NV
 #undef LAUNCH_LIKE
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -475,13 +519,16 @@ int launch_like(relate_hip_t h, int nl, const LikeIO &io) {
   return 0;
 }
 // lanes already uploaded to dLanePair/dParams; result in dOut (device)
-int launch_like(relate_hip_t h, int P, int nl) {
+int launch_like(relate_hip_t h, int P, int nl, int nv_max = 1) {
   (void)P;
-  return launch_like(h, nl, LikeIO{LaneMap{h->dLanePair.p, 1}, h->dParams.p, h->dOut.p, nullptr, 0});
+  return launch_like(h, nl, LikeIO{LaneMap{h->dLanePair.p, 1}, h->dParams.p, h->dOut.p, nullptr, 0, pick_nv(nl, nv_max)});
 }
+// E points per pair in order: the largest lane width that never straddles two pairs
+inline int nv_for_points(int E) { return E % 2 == 0 ? 2 : 1; }
 
 // K5 on the staged block: nl lanes, host arrays in, host array out
-int like_lanes(relate_hip_t h, int P, const int32_t *lane_pair, const double *params, int nl, double *out) {
+int like_lanes(relate_hip_t h, int P, const int32_t *lane_pair, const double *params, int nl, double *out,
+               int nv_max = 1) {
   if (nl == 0) return 0;
   HIPCHK(h, h->dLanePair.ensure(nl));
   HIPCHK(h, h->dParams.ensure((size_t)3 * nl));
@@ -489,7 +536,7 @@ int like_lanes(relate_hip_t h, int P, const int32_t *lane_pair, const double *pa
   HIPCHK(h, hipMemcpyAsync(h->dLanePair.p, lane_pair, sizeof(int32_t) * nl, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->dParams.p, params, sizeof(double) * 3 * nl, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-  int rc = launch_like(h, P, nl);
+  int rc = launch_like(h, P, nl, nv_max);
   if (rc) return rc;
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
   HIPCHK(h, hipMemcpyAsync(out, h->dOut.p, sizeof(double) * nl, hipMemcpyDeviceToHost, h->stream));
@@ -520,7 +567,7 @@ int like_enqueue(relate_hip_t h, int P, LaneBufs &B) {
   HIPCHK(h, hipMemcpyAsync(h->dLanePair.p, B.lane, sizeof(int32_t) * nl, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->dParams.p, B.par, sizeof(double) * 3 * nl, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipEventRecord(B.e0, h->stream));
-  int rc = launch_like(h, P, nl);
+  int rc = launch_like(h, nl, LikeIO{LaneMap{h->dLanePair.p, 1}, h->dParams.p, h->dOut.p, nullptr, 0, B.nv});
   if (rc) return rc;
   B.chunks = h->last_chunks[0];
   HIPCHK(h, hipEventRecord(B.e1, h->stream));
@@ -540,6 +587,8 @@ int like_wait(relate_hip_t h, LaneBufs &B) {
 
 // One population of pairs of the staged block with its optimiser state: prepare() advances the multi-start rule,
 // starts and retires runs and lays out the lanes of the next likelihood launch; consume() feeds the values back.
+constexpr long kCompactBelowPoints = 45056;  // launches below this size are cut along the SNP axis (pick_chunks)
+
 struct FitPop {
   struct Run {
     FindMax fm;
@@ -567,6 +616,11 @@ struct FitPop {
   std::vector<Run *> active;
   bool first_round = true, inflight = false, finished = false;
   LaneBufs *B = nullptr;
+  std::vector<int> col;                          // column of every pair in the record block
+  int ncols = 0;                                 // columns [p0, p0 + ncols) hold this population's live pairs
+  std::function<int(FitPop &, const std::vector<int> &)> restage;  // stages the given pairs into columns p0, p0 + 1, ...
+  int ul = 2;                                    // slots per pair of the uLike / poLike points in the first launch
+  std::vector<std::pair<size_t, size_t>> pads;   // slot gaps [first, second) of the launch being laid out
 
   ~FitPop() {
     for (Run *r : active) delete r;
@@ -591,6 +645,9 @@ struct FitPop {
     }
     results.assign(P, std::vector<double>((size_t)R * 4, 0.0));
     have.assign(P, std::vector<char>(R, 0));
+    col.resize(P);
+    for (int p = 0; p < P; p++) col[p] = p0 + p;
+    ncols = P;
   }
 
   // returns the number of lanes laid out in B, or -1 on a pinned-memory error; sets `finished` when no run is left.
@@ -654,12 +711,12 @@ struct FitPop {
       finished = true;
       return 0;
     }
-    // Whole turns of the machine.  A single sweep costs the time of its fullest SIMD: 100 000 steps take 10.4 ms
-    // with up to one wave per SIMD (65 536 lanes), 17.5 ms with up to two, 26 ms with up to three, so 70 000 lanes
-    // cost as much as 131 072.  A round with more than one full turn of requests launches whole turns only and
-    // holds the rest back one round (runs are independent state machines; a held request is simply answered later,
-    // with the same values).  Held runs go first in the next round, so none waits twice.
-    const long kTurn = 256L * 4 * 64;
+    // Whole turns of the machine.  A single sweep costs the time of its fullest SIMD, so a launch of 1.1 waves per
+    // SIMD costs what one of 2.0 does.  Up to one turn of lanes at two points per lane (131 072 points) a round
+    // launches what it has (two-sided sweep: the cost follows the count); beyond, whole turns only, and the rest is
+    // held back one round (runs are independent state machines; a held request is simply answered later, with the
+    // same values).  Held runs go first in the next round, so none waits twice.
+    const long kTurn = 2 * 256L * 4 * 64;
     parallel_for(active.size(), [&](size_t lo_, size_t hi_) {
       for (size_t i = lo_; i < hi_; i++) {  // lanes a run needs: the points its wrapper does not short-circuit
         Run *r = active[i];
@@ -672,6 +729,20 @@ struct FitPop {
     });
     long want = 0;
     for (Run *r : active) want += r->nlanes;
+    // Few pairs left, scattered over the block's columns: every lane then pulls whole 128-byte lines for the 16 bytes
+    // of its pair (a launch of 1 300 points over 260 scattered pairs ran HBM-bound at 136 G point-steps/s against
+    // ~460 G dense).  Once the live pairs are a quarter of the columns they occupy, their records are staged again
+    // side by side (K4 from the genotypes: ~3 us per pair at M = 5e5); finished pairs no longer need theirs.
+    if (!first_round && restage && want > 0 && want < kCompactBelowPoints) {
+      std::vector<int> live;
+      for (int p = 0; p < P; p++)
+        if (!ms[p].finished) live.push_back(p);
+      if (!live.empty() && (long)live.size() * 4 <= ncols) {
+        if (restage(*this, live)) return -2;
+        for (size_t i = 0; i < live.size(); i++) col[live[i]] = p0 + (int)i;
+        ncols = (int)live.size();
+      }
+    }
     long budget = (!first_round && want > kTurn) ? (want / kTurn) * kTurn : want;
     long used = 0;
     for (Run *r : active) {
@@ -685,21 +756,36 @@ struct FitPop {
         used += r->nlanes;
       }
     }
-    // uLike / poLike (:3478-3481) ride along with the first launch: lanes 2p, 2p+1
-    size_t nl_total = first_round ? (size_t)2 * P : 0;
+    // Slots.  A lane of the likelihood kernels may carry nv points of one pair (pick_nv): every pair's points start at
+    // a multiple of nv and are padded to one with copies of its last point (values never read).
+    // uLike / poLike (:3478-3481) ride along with the first launch: slots p * ul, p * ul + 1
+    const int nv = pick_nv(used + (first_round ? 2L * P : 0), 2);
+    auto up = [nv](size_t x) { return (x + nv - 1) / nv * nv; };
+    B->nv = nv;
+    ul = (int)up(2);
+    size_t nl_total = first_round ? (size_t)ul * P : 0;
+    pads.clear();
+    int prev_pair = -1;
     for (Run *r : active) {
       r->waited = !r->taken;
+      if (r->taken && r->nlanes > 0 && r->pair != prev_pair) {
+        if (nl_total % nv) pads.push_back({nl_total, up(nl_total)});
+        nl_total = up(nl_total);
+        prev_pair = r->pair;
+      }
       r->lane0 = nl_total;
       if (r->taken) nl_total += r->nlanes;
     }
+    if (nl_total % nv) pads.push_back({nl_total, up(nl_total)});
+    nl_total = up(nl_total);
     if (B->ensure(nl_total) != hipSuccess) return -1;
     B->nl = (int)nl_total;
     if (first_round)
       for (int p = 0; p < P; p++)
-        for (int j = 0; j < 2; j++) {
-          size_t at = (size_t)2 * p + j;
+        for (int j = 0; j < ul; j++) {
+          size_t at = (size_t)ul * p + j;
           B->lane[at] = p0 + p;
-          B->par[3 * at] = o->alim[0]; B->par[3 * at + 1] = 0; B->par[3 * at + 2] = j;
+          B->par[3 * at] = o->alim[0]; B->par[3 * at + 1] = 0; B->par[3 * at + 2] = j < 2 ? j : 1;
         }
     parallel_for(active.size(), [&](size_t lo_, size_t hi_) {
       for (size_t i = lo_; i < hi_; i++) {
@@ -710,13 +796,18 @@ struct FitPop {
           r->slot[q] = -1;
           if (r->ok[q]) {
             r->slot[q] = (int)at;
-            B->lane[at] = p0 + r->pair;
+            B->lane[at] = col[r->pair];
             B->par[3 * at] = r->akk[q][0]; B->par[3 * at + 1] = r->akk[q][1]; B->par[3 * at + 2] = r->akk[q][2];
             at++;
           }
         }
       }
     });
+    for (const auto &g : pads)  // a gap follows the last point of a pair: copy that point
+      for (size_t at = g.first; at < g.second; at++) {
+        B->lane[at] = B->lane[g.first - 1];
+        for (int c = 0; c < 3; c++) B->par[3 * at + c] = B->par[3 * (g.first - 1) + c];
+      }
     return (long)nl_total;
   }
 
@@ -724,8 +815,8 @@ struct FitPop {
     const double *val = B->val;
     if (first_round) {
       for (int p = 0; p < P; p++) {
-        out[p0 + p].uLike = val[2 * p];
-        out[p0 + p].poLike = val[2 * p + 1];
+        out[p0 + p].uLike = val[(size_t)ul * p];
+        out[p0 + p].poLike = val[(size_t)ul * p + 1];
       }
       first_round = false;
     }
@@ -820,14 +911,30 @@ int fit_block(relate_hip_t h, int P, long pair_base, const double *starts, relat
   int npop = P >= 16384 ? 2 : 1;
   if (const char *e = getenv("RELATE_FIT_POPULATIONS")) npop = atoi(e) >= 2 && P >= 2 ? 2 : 1;
   FitPop pop[2];
+  const std::vector<int32_t> blk(h->staged);  // the block's pairs by column (compaction clears the memo)
+  static const bool compact = [] { const char *e = getenv("RELATE_FIT_COMPACT"); return !(e && atoi(e) == 0); }();
   for (int k = 0; k < npop; k++) {
     int b = (int)((long)P * k / npop), e = (int)((long)P * (k + 1) / npop);
     pop[k].init(b, e - b, &o, S, starts, pair_base, &h->lanebufs[k], h->h_nsnp.data());
+    if (compact && (int)blk.size() == 2 * P)
+      pop[k].restage = [h, &blk](FitPop &F, const std::vector<int> &live) -> int {
+        std::vector<int32_t> sub(2 * live.size());
+        for (size_t i = 0; i < live.size(); i++) {
+          sub[2 * i] = blk[2 * (size_t)(F.p0 + live[i])];
+          sub[2 * i + 1] = blk[2 * (size_t)(F.p0 + live[i]) + 1];
+        }
+        h->staged.clear();  // the block in dRec is no longer the one the memo describes
+        const double t_stage = h->timings[0];
+        int rc = stage_cols(h, sub.data(), (int)live.size(), F.p0, h->recPitch, false);
+        h->timings[0] += t_stage;
+        return rc;
+      };
   }
   auto start = [&](FitPop &F) -> int {
     F.inflight = false;
     for (;;) {
       long nl = F.prepare();
+      if (nl == -2) return RELATE_E_HIP;  // staging the live pairs again failed: the message is set
       if (nl < 0) return fail(h, RELATE_E_NOMEM, "pinned host memory for the likelihood lanes");
       if (F.finished) return 0;
       if (nl > 0) {
@@ -1466,7 +1573,7 @@ int relate_hip_like(relate_hip_t h, const int32_t *pairs, int P, const double *p
     lp.resize((size_t)pb * E);
     for (int p = 0; p < pb; p++)
       for (int e = 0; e < E; e++) lp[(size_t)p * E + e] = p;
-    rc = like_lanes(h, pb, lp.data(), params + (size_t)b0 * E * 3, pb * E, negloglik + (size_t)b0 * E);
+    rc = like_lanes(h, pb, lp.data(), params + (size_t)b0 * E * 3, pb * E, negloglik + (size_t)b0 * E, nv_for_points(E));
     if (rc) return rc;
   }
   return RELATE_OK;
@@ -1570,7 +1677,15 @@ int relate_hip_run_pairs(relate_hip_t h, const int32_t *pairs, int P, const doub
         const relate_fit &f = out[b0 + c0 + p];
         par[3 * p] = f.a; par[3 * p + 1] = f.k2; par[3 * p + 2] = f.k1;
       }
-      rc = decode_block(h, pairs + 2 * (b0 + c0), (int)c0, pc, par.data(),
+      // the fit stages the last live pairs of a block again, side by side (FitPop::prepare): then the block's records
+      // are gone and the sub-block is staged afresh
+      int col0 = (int)c0;
+      if ((int)h->staged.size() != 2 * pb) {
+        rc = stage_block(h, pairs + 2 * (b0 + c0), pc);
+        if (rc) return rc;
+        col0 = 0;
+      }
+      rc = decode_block(h, pairs + 2 * (b0 + c0), col0, pc, par.data(),
                         post ? post + (size_t)(b0 + c0) * 3 * h->M : nullptr,
                         path ? path + (size_t)(b0 + c0) * h->M : nullptr, nullptr, true);
       if (rc) return rc;
@@ -1643,7 +1758,7 @@ int relate_hip_bench_like(relate_hip_t h, const int32_t *pairs, int P, const dou
   HIPCHK(h, hipMemcpyAsync(h->dParams.p, params, sizeof(double) * 3 * nl, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   for (int r = 0; r < reps; r++) {
-    rc = launch_like(h, P, nl);
+    rc = launch_like(h, P, nl, nv_for_points(E));
     if (rc) return rc;
   }
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));

@@ -260,16 +260,17 @@ def test_scale_properties_chunked_equals_unchunked(gpu, oracle):
     E = 70
     big = np.broadcast_to(par[0], (len(many), E, 3)).copy()
     big[:, 1] = par[1]
-    bvals = gpu.like(many, big)                                               # 420k lanes -> single sweep
+    bvals = gpu.like(many, big)                                               # 420k points -> single sweep, two per lane
     np.testing.assert_allclose(bvals[:3, 0], a[:, 0], rtol=1e-12)
     np.testing.assert_allclose(bvals[:3, 1], a[:, 1], rtol=1e-12)
     assert np.ptp(bvals[:, 2:], axis=1).max() == 0                            # identical lanes, identical values
-    # the single sweep has builds by ring depth (two / three or more waves per SIMD): 105 000 lanes take the other
-    # one; the arithmetic is the same instruction sequence, so the values are bit-identical.  63 000 lanes (up to one
-    # wave per SIMD) take the two-sided sweep (forward half . backward half): equal to rounding
-    v = gpu.like(many[:1500], big[:1500])
+    # the single sweep has builds by ring depth (two / three or more waves per SIMD): 154 000 points (77 000 lanes of
+    # two) take the other one; the arithmetic is the same instruction sequence on the same lane grouping, so the values
+    # are bit-identical.  63 000 points (up to one wave per SIMD) take the two-sided sweep (forward half . backward
+    # half): equal to rounding
+    v = gpu.like(many[:2200], big[:2200])
     assert gpu.last_chunks()[0] == 1
-    assert np.array_equal(v, bvals[:1500])
+    assert np.array_equal(v, bvals[:2200])
     v = gpu.like(many[:900], big[:900])
     assert gpu.last_chunks()[0] == 1
     np.testing.assert_allclose(v, bvals[:900], rtol=1e-13)
