@@ -535,7 +535,7 @@ int main(int argc, char **argv) {
   std::vector<int> ns((size_t)B);
   std::vector<char> text;           // formatted rows of a group of pairs (write_post_block)
   std::vector<size_t> text_len;
-  int bad = 0;
+  int bad = 0, nosnp = 0;
   for (long f0 = 0; f0 < P; f0 += FB) {
     const long nf = std::min<long>(FB, P - f0);
     if (relate_hip_fit(h, &pairs[2 * f0], (int)nf, nullptr, fitv.data(), nullptr)) die(relate_hip_last_error(h));
@@ -543,14 +543,14 @@ int main(int argc, char **argv) {
       int nb = (int)std::min<long>(B, f0 + nf - b0);
       relate_fit *fit = &fitv[(size_t)(b0 - f0)];
       for (int p = 0; p < nb; p++) { par[3 * p] = fit[p].a; par[3 * p + 1] = fit[p].k2; par[3 * p + 2] = fit[p].k1; }
-      if (fpost || fest) {  // the posterior rows, and the SNP count of the .est line
+      if (fpost) {  // the posterior rows (the SNP count of the .est line comes with the fit)
         if (relate_hip_decode(h, &pairs[2 * b0], nb, par.data(), post, nullptr, ns.data()))
           die(relate_hip_last_error(h));
-        for (int p = 0; p < nb; p++) fit[p].nsnp = ns[p];
       }
       if (fpost) write_post_block(fpost, post, nb, M, k1_only, text, text_len);
       for (int p = 0; p < nb; p++) {
-        if (fit[p].status) bad++;
+        if (fit[p].status == RELATE_E_NOSNP) nosnp++;
+        else if (fit[p].status) bad++;
         if (fk) {
           // batch drivers: setprecision(POSTPRECISION) (src/relateHMM.cpp:142); lone pair: default precision
           // (src/runRelate.cpp:70)
@@ -571,6 +571,8 @@ int main(int argc, char **argv) {
   }
   if (verbose) std::printf("\n");
   if (bad) std::printf("\t-> %d pair(s) hit a NaN in the recursion (the reference would have exited there)\n", bad);
+  if (nosnp)  // src/relateHMM.cpp:3415-3421: the reference stops at the first such pair
+    std::printf("\t-> %d pair(s) don't share 1 non-missing SNP: not fitted, rows of -1 (the reference would have exited there)\n", nosnp);
   if (fpost) std::fclose(fpost);
   if (fk) std::fclose(fk);
   if (fest) std::fclose(fest);

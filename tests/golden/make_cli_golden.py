@@ -5,6 +5,14 @@ on the fixture data.  Run here, in the build container; the outputs are committe
 
     c5_*  config 5: options.linkage.txt -file dat_small -d dat_small.keep   (190 pairs, pruned to 415 SNPs)
     c1_*  config 1: options.single.pair.txt -file dat_small -choose 0       (pair (0,1) through init_globals + sgl)
+    c1b_* config 1 as BASELINE.json states it: the same command without -choose 0, i.e. the program's default route
+          for a lone pair, single_pair / getPars (src/runRelate.cpp:419-420, src/relateHMM.cpp:3595-3737, 3049-3223):
+          the fixture that pins "the legacy route equals init_globals + sgl on this data" 
+    c2_*  config 2: options.all.pair.txt -file dat_small -d dat_small.keep  (README.md:71; 190 pairs, 2-parameter calcA
+          mode, ~70 s on one core): stripped dumps, keep.index, the .k file, and of the 2.6 MB .post file only what is
+          stable -- per pair the SNPs printed as -1 (c2_post_dropped.json); the reference's -logL per pair, which its
+          program never prints, comes from the same sources through the harness with the same pinned seed
+          (c2_ref_fit.json: a, k2, k1, -logL, timesRun, timesConverged)
     c3_*  config 3: options.all.pair.txt -plink 500                         (66 pairs; chaotic 2-parameter mode:
                                                                              kept for the stripped dumps and format)
     c6_*  synthetic PLINK files data/syn6.* (16 individuals x 1500 .bim lines in shuffled order, chromosomes 0, 23
@@ -31,6 +39,9 @@ RUNS = {
     "c1": ["-o", DATA + "/options.single.pair.txt", "-file", DATA + "/dat_small", "-choose", "0",
            "-post", "out.post", "-k", "out.k"],
     "c3": ["-o", DATA + "/options.all.pair.txt", "-plink", DATA + "/500", "-post", "out.post", "-k", "out.k"],
+    "c1b": ["-o", DATA + "/options.single.pair.txt", "-file", DATA + "/dat_small", "-post", "out.post", "-k", "out.k"],
+    "c2": ["-o", DATA + "/options.all.pair.txt", "-file", DATA + "/dat_small", "-d", DATA + "/dat_small.keep",
+           "-post", "out.post", "-k", "out.k"],
 }
 
 if not os.path.exists(DATA + "/syn6.bed"):
@@ -82,8 +93,38 @@ for name, args in RUNS.items():
         subprocess.run([REF] + args, cwd=td, env=env, check=True, stdout=subprocess.DEVNULL)
         for f in ("out.post", "out.k", "stripped.geno", "stripped.pos", "stripped.chr", "keep.index"):
             src = os.path.join(td, f)
+            if name == "c2" and f == "out.post":  # keep the dropped-SNP pattern of every pair (rows IBD0, IBD1 per pair)
+                import json
+                rows = [ln.split("\t") for ln in open(src).read().splitlines()]
+                drop = [[i for i, v in enumerate(r) if v.strip() == "-1"] for r in rows]
+                assert all(a == b for a, b in zip(drop[0::2], drop[1::2])) and len(rows) == 380
+                with open(os.path.join(OUT, "c2_post_dropped.json"), "w") as fh:
+                    json.dump({"rows": len(rows), "cols": len([v for v in rows[0] if v.strip()]), "dropped": drop[0::2]}, fh)
+                continue
             if name in ("c3", "c6", "c7", "c8") and f == "out.post":
                 continue  # 0.5 MB of posteriors at chaotic estimates: not a usable pin
             if os.path.exists(src):
                 shutil.copy(src, os.path.join(OUT, "%s_%s" % (name, f)))
+# c2: the reference's full-precision fit per pair through the harness (same sources, same pinned seed)
+import json  # noqa: E402
+import sys  # noqa: E402
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import pathcheck as pc  # noqa: E402
+import refload  # noqa: E402
+ref = refload.Ref()
+g, pos, chr_ = refload.load_dataset("dat_small")
+opt = dict(pc.options("options.all.pair.txt"))
+pairs = [tuple(int(v) for v in p) for p in refload.keep_pairs(os.path.join(DATA, "dat_small.keep"))]
+ref.init(g, pos, chr_, opt)
+try:
+    fit = []
+    for i, j in pairs:
+        x = ref.sgl(i, j, seed=4242)
+        fit.append({"pair": [i, j], "a": x["a"], "k2": x["k2"], "k1": x["k1"], "nll": x["nll"],
+                    "timesRun": x["timesRun"], "timesConv": x["timesConv"]})
+finally:
+    ref.fini()
+with open(os.path.join(OUT, "c2_ref_fit.json"), "w") as fh:
+    json.dump({"options": "options.all.pair.txt", "seed": 4242, "pairs": fit}, fh)
 print(sorted(os.listdir(OUT)))
