@@ -176,6 +176,18 @@ int relate_format_post_rows(const double *post, int P, int M, int k1_only, char 
 /* Rank r of nranks owns pairs [*begin, *end) of a list of P pairs. */
 void relate_hip_shard(int64_t P, int rank, int nranks, int64_t *begin, int64_t *end);
 
+/* The path's one exchange: all-gather of the per-pair result records, rank r contributing the records of its
+ * relate_hip_shard(P_total, r, nranks) range; `all` (P_total records) is complete on every rank when the call
+ * returns.  The reference has no counterpart: its pair loop is one process (src/relateHMM.cpp:3764-3785); this is
+ * the seam at which that loop is cut into pair blocks per GPU.  transport 0: RCCL (xGMI inside a node) on the
+ * handle's GPU and stream -- one communicator per handle, made at the first call from a ncclUniqueId that rank 0
+ * leaves in the file <rendezvous>.g<call>.id; librccl.so is looked up at run time (no link dependency).  transport 1:
+ * the records travel through files <rendezvous>.g<call>.fit.<rank> on a filesystem every rank sees (h may be NULL):
+ * for ranks that share one GPU, and for tests.  rendezvous may be NULL when nranks == 1.  Waits for the other ranks
+ * up to RELATE_GATHER_TIMEOUT seconds (default 1800). */
+int relate_hip_gather(relate_hip_t h, const relate_fit *mine, int64_t P_total, int rank, int nranks,
+                      const char *rendezvous, int transport, relate_fit *all);
+
 /* ---- linkage statistic + permutation test on posterior rows (next row of the path: the reference's HMMtest) ------ */
 /* uber_main, case-control design (src/HMMtest.txt:1195-1367).  post: R x M floats, row p = the IBD0 posterior row of
  * pair p as the .post file holds it (-1 = SNP dropped for the pair), pairs in the all-pairs order of the n_ind

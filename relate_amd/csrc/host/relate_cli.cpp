@@ -377,7 +377,11 @@ void usage() {
       "\t-post POSTOUTPUT -k KOUTPUT | -file PREFIX | -out PREFIX\n"
       "\tSYNTAX: plink binary files\n\t./relateHMM_hip -o OPTION -plink PREFIX (or -plink-bed/-plink-bim/-plink-fam)\n"
       "\textra: -seed N (pin the start points), -gpu D (device ordinal), -est FILE (a, k2, k1, -logL, runs per pair),\n"
-      "\t       -post-block N (pairs per posterior decode call)\n");
+      "\t       -post-block N (pairs per posterior decode call)\n"
+      "\tmulti-GPU: one process per GPU, -rank R -nranks N (default: RANK / WORLD_SIZE of the environment); every rank\n"
+      "\t       takes a contiguous shard of the pair list and writes its posterior rows to POSTOUTPUT.rankR; the\n"
+      "\t       estimates are gathered (-gather rccl | file, rendezvous files next to -rdv PATH) and rank 0 writes\n"
+      "\t       KOUTPUT and the -est file for all pairs\n");
 }
 
 std::string strip_ext(const std::string &p, std::initializer_list<const char *> exts) {
@@ -401,6 +405,10 @@ int main(int argc, char **argv) {
   long post_block = 0;  // -post-block: pairs per decode call (default: what ~1 GiB of posterior rows holds)
   bool have_seed = false;
   unsigned seed = 0;
+  auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e && *e ? std::atoi(e) : dflt; };
+  int rank = env_int("RANK", 0), nranks = env_int("WORLD_SIZE", 1);
+  bool have_gpu = false;
+  std::string gatherT = "rccl", rdv;
   for (int a = 1; a < argc; a += 2) {
     std::string f = argv[a];
     if (f == "--help") { usage(); return 0; }
@@ -429,14 +437,22 @@ int main(int argc, char **argv) {
     } else if (f == "-choose") { /* both routes are the fast one here */ }
     else if (f == "-d") keepfile = v;
     else if (f == "-seed") { seed = (unsigned)std::strtoul(v.c_str(), nullptr, 10); have_seed = true; }
-    else if (f == "-gpu") device = std::atoi(v.c_str());
+    else if (f == "-gpu") { device = std::atoi(v.c_str()); have_gpu = true; }
+    else if (f == "-rank") rank = std::atoi(v.c_str());
+    else if (f == "-nranks") nranks = std::atoi(v.c_str());
+    else if (f == "-gather") gatherT = v;
+    else if (f == "-rdv") rdv = v;
     else if (f == "-est") estF = v;
     else if (f == "-post-block") post_block = std::atol(v.c_str());
     else { std::printf("\nArgument unknown will exit: %s \n", argv[a]); usage(); return 1; }
   }
+  if (nranks < 1 || rank < 0 || rank >= nranks) die("-rank must lie in 0 .. -nranks - 1");
+  if (gatherT != "rccl" && gatherT != "file") die("-gather takes rccl or file");
+  if (!have_gpu && nranks > 1) device = env_int("LOCAL_RANK", rank);  // one process per GPU
   if (verbose) {
     time_t t = time(nullptr);
     std::printf("\t-> relateHMM_hip (C ABI over gfx950 kernels; reference CLI 0.992 semantics)\t%s", ctime(&t));
+    if (nranks > 1) std::printf("\t-> rank %d of %d on GPU %d\n", rank, nranks, device);
   }
   DataSet d;
   const bool chr_given = !chr.empty();
@@ -502,24 +518,39 @@ int main(int argc, char **argv) {
   } else {
     pairs = {op.pair[0], op.pair[1]};
   }
+  // Multi-GPU (no counterpart in the reference, whose pair loop is one process: src/relateHMM.cpp:3764-3785,
+  // 3851-3875): rank r takes the contiguous shard relate_hip_shard gives it.  Every rank loads the data set and
+  // runs the pre-calculation itself (inputs are replicated, nothing is exchanged until the estimates are gathered).
+  const long Pall = (long)pairs.size() / 2;
+  int64_t sb = 0, se = Pall;
+  relate_hip_shard(Pall, rank, nranks, &sb, &se);
+  const std::vector<int32_t> all_pairs = pairs;
+  pairs.assign(all_pairs.begin() + 2 * sb, all_pairs.begin() + 2 * se);
   const long P = (long)pairs.size() / 2;
-  if (batch) {
+  if (nranks > 1 && !batch) die("-nranks > 1 needs a pair list (all pairs or -d)");
+  if (rdv.empty()) rdv = kF + ".rdv";
+  if (batch && rank > 0) {  // the dumps and the names of the outputs are rank 0's business
+    postF = postF + ".rank" + std::to_string(rank);
+    std::printf("\t-> rank %d: pairs %ld .. %ld of %ld\n", rank, (long)sb, (long)se, Pall);
+  } else if (batch) {
     std::printf("\t-> Will dump these data, that are used for analysis after the maf/prune removal\n");
     if (!keepfile.empty()) { sg = "stripped.geno"; sp = "stripped.pos"; sc = "stripped.chr"; sk = "keep.index"; }
     std::printf("\t\tgeno:\t\"%s\"\n\t\tchromo:\t\"%s\"\n\t\tpos:\t\"%s\"\n\t\tkeepList:\"%s\"\n", sg.c_str(), sc.c_str(),
                 sp.c_str(), sk.c_str());
     // (joblist_fast_all_pairs dumps to the default names whatever -out says, src/relateHMM.cpp:3832-3839)
     dump_stripped(h, d, keep, M, sg, sp, sc, sk);
-    postF = fresh_name(postF);
+    // (with several ranks the row shards keep the name given, so that rank r's file is POSTOUTPUT.rank<r> for all r)
+    postF = nranks > 1 ? postF + ".rank0" : fresh_name(postF);
     kF = fresh_name(kF);
-    std::printf("\t-> number of individuals:%d\n\t-> number of pairs to run:%ld\n", d.N, P);
+    std::printf("\t-> number of individuals:%d\n\t-> number of pairs to run:%ld\n", d.N, Pall);
   } else {
     if (file_exists(kF)) std::printf("\t-> Filename: %s exists will append new results to file\n", kF.c_str());
     if (file_exists(postF)) std::printf("\t-> Filename: %s exists will append new results to file\n", postF.c_str());
   }
   FILE *fpost = postF.empty() ? nullptr : std::fopen(postF.c_str(), "a");
-  FILE *fk = kF.empty() ? nullptr : std::fopen(kF.c_str(), "a");
-  FILE *fest = estF.empty() ? nullptr : std::fopen(estF.c_str(), "w");
+  FILE *fk = kF.empty() || rank > 0 ? nullptr : std::fopen(kF.c_str(), "a");
+  FILE *fest = estF.empty() || rank > 0 ? nullptr : std::fopen(estF.c_str(), "w");
+  if (rank > 0) { kF.clear(); estF.clear(); }
   if ((!postF.empty() && !fpost) || (!kF.empty() && !fk) || (!estF.empty() && !fest)) die("cannot open output files");
   const bool k1_only = op.o.fixK == 1 && op.o.fixK_val == 0;  // :3771
   // The fit takes the pairs in large blocks (its launches need tens of thousands of pairs in flight to fill the
@@ -527,7 +558,7 @@ int main(int argc, char **argv) {
   const long FB = std::max<long>(1, std::min<long>(P, 65536));
   long B = std::max<long>(1, std::min<long>(FB, ((long)1 << 30) / ((long)3 * M * (long)sizeof(double))));
   if (post_block > 0) B = std::min<long>(FB, post_block);
-  std::vector<relate_fit> fitv((size_t)FB);
+  std::vector<relate_fit> mine((size_t)std::max<long>(P, 1));  // this rank's records, in pair order
   std::vector<double> par((size_t)B * 3);
   double *post = nullptr;  // page-locked: the posterior rows arrive by direct DMA
   if (fpost && relate_hip_host_alloc((void **)&post, (size_t)B * 3 * M * sizeof(double)))
@@ -538,31 +569,16 @@ int main(int argc, char **argv) {
   int bad = 0, nosnp = 0;
   for (long f0 = 0; f0 < P; f0 += FB) {
     const long nf = std::min<long>(FB, P - f0);
-    if (relate_hip_fit(h, &pairs[2 * f0], (int)nf, nullptr, fitv.data(), nullptr)) die(relate_hip_last_error(h));
+    if (relate_hip_fit(h, &pairs[2 * f0], (int)nf, nullptr, &mine[(size_t)f0], nullptr)) die(relate_hip_last_error(h));
     for (long b0 = f0; b0 < f0 + nf; b0 += B) {
       int nb = (int)std::min<long>(B, f0 + nf - b0);
-      relate_fit *fit = &fitv[(size_t)(b0 - f0)];
+      relate_fit *fit = &mine[(size_t)b0];
       for (int p = 0; p < nb; p++) { par[3 * p] = fit[p].a; par[3 * p + 1] = fit[p].k2; par[3 * p + 2] = fit[p].k1; }
       if (fpost) {  // the posterior rows (the SNP count of the .est line comes with the fit)
         if (relate_hip_decode(h, &pairs[2 * b0], nb, par.data(), post, nullptr, ns.data()))
           die(relate_hip_last_error(h));
       }
       if (fpost) write_post_block(fpost, post, nb, M, k1_only, text, text_len);
-      for (int p = 0; p < nb; p++) {
-        if (fit[p].status == RELATE_E_NOSNP) nosnp++;
-        else if (fit[p].status) bad++;
-        if (fk) {
-          // batch drivers: setprecision(POSTPRECISION) (src/relateHMM.cpp:142); lone pair: default precision
-          // (src/runRelate.cpp:70)
-          int prec = batch ? 4 : 6;
-          put_g(fk, fit[p].k1, prec); std::fputc('\n', fk);
-          if (!k1_only) { put_g(fk, fit[p].k2, prec); std::fputc('\n', fk); }
-        }
-        if (fest)
-          std::fprintf(fest, "%d\t%d\t%.17g\t%.17g\t%.17g\t%.17g\t%d\t%d\t%d\t%d\n", pairs[2 * (b0 + p)],
-                       pairs[2 * (b0 + p) + 1], fit[p].a, fit[p].k2, fit[p].k1, fit[p].negloglik, fit[p].timesRun,
-                       fit[p].timesConverged, fit[p].nsnp, fit[p].status);
-      }
       if (verbose) {
         std::printf("\r\t-> %ld/%ld pairs ", b0 + nb, P);
         std::fflush(stdout);
@@ -570,6 +586,31 @@ int main(int argc, char **argv) {
     }
   }
   if (verbose) std::printf("\n");
+  // the estimates of all ranks, in pair order, on every rank (the path's one exchange); rank 0 writes them
+  std::vector<relate_fit> gathered;
+  const relate_fit *allfit = mine.data();
+  if (nranks > 1) {
+    gathered.resize((size_t)std::max<long>(Pall, 1));
+    if (relate_hip_gather(h, mine.data(), Pall, rank, nranks, rdv.c_str(), gatherT == "file" ? 1 : 0, gathered.data()))
+      die(relate_hip_last_error(h));
+    allfit = gathered.data();
+  }
+  if (rank == 0)
+    for (long p = 0; p < Pall; p++) {
+      const relate_fit &f = allfit[p];
+      if (f.status == RELATE_E_NOSNP) nosnp++;
+      else if (f.status) bad++;
+      if (fk) {
+        // batch drivers: setprecision(POSTPRECISION) (src/relateHMM.cpp:142); lone pair: default precision
+        // (src/runRelate.cpp:70)
+        int prec = batch ? 4 : 6;
+        put_g(fk, f.k1, prec); std::fputc('\n', fk);
+        if (!k1_only) { put_g(fk, f.k2, prec); std::fputc('\n', fk); }
+      }
+      if (fest)
+        std::fprintf(fest, "%d\t%d\t%.17g\t%.17g\t%.17g\t%.17g\t%d\t%d\t%d\t%d\n", all_pairs[2 * p], all_pairs[2 * p + 1],
+                     f.a, f.k2, f.k1, f.negloglik, f.timesRun, f.timesConverged, f.nsnp, f.status);
+    }
   if (bad) std::printf("\t-> %d pair(s) hit a NaN in the recursion (the reference would have exited there)\n", bad);
   if (nosnp)  // src/relateHMM.cpp:3415-3421: the reference stops at the first such pair
     std::printf("\t-> %d pair(s) don't share 1 non-missing SNP: not fitted, rows of -1 (the reference would have exited there)\n", nosnp);

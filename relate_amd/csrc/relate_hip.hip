@@ -7,6 +7,11 @@
 #include "../../include/relate_hip_bench.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is looked up at run time (relate_hip_gather)
+
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -147,6 +152,10 @@ struct relate_hip_ctx {
   double timings[4] = {0, 0, 0, 0};
   int last_chunks[2] = {1, 1};  // SNP-axis chunks of the last like / decode launch
   long slots_like = 2048, slots_decode = 6144;  // resident waves of the chunked sweeps (set at create)
+  ncclComm_t comm = nullptr;  // relate_hip_gather: one communicator per handle, made at the first gather
+  int comm_rank = -1, comm_n = 0;
+  long gather_seq = 0;        // gathers issued on this handle (names the rendezvous files of each)
+  DBuf<unsigned char> dGatherS, dGatherR;
   unsigned char *scratch_dev = nullptr;  // device address of `scratch` on this handle's GPU (relate_hip_like_noalloc)
   long single_sweep_lanes = 45056;              // launches below this many lanes are cut along the SNP axis (pick_chunks)
 };
@@ -1113,6 +1122,8 @@ int decode_block(relate_hip_t h, const int32_t *pairs, int p0, int P, const doub
   return 0;
 }
 
+void gather_release(relate_hip_t h);
+
 }  // namespace
 
 extern "C" {
@@ -1180,6 +1191,7 @@ int relate_hip_destroy(relate_hip_t h) {
   }
   for (int i = 0; i < 4; i++)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+  gather_release(h);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RELATE_OK;
@@ -1985,6 +1997,152 @@ extern "C" int relate_hip_linkage(relate_hip_t h, const float *post, int R, int 
     res->psigsim = (at >= 0 && at < nsim) ? sorted[at] : NAN;
     res->n_case_pairs = n_case;
     res->n_control_pairs = n_ctrl;
+  }
+  return RELATE_OK;
+}
+
+// ---- multi-GPU: the path's one exchange -------------------------------------------------------------------------
+// Pairs are independent, so ranks work on contiguous shards of the pair list (relate_hip_shard) and meet once, to
+// gather the per-pair result records.  Over RCCL (xGMI inside a node): one all-gather of the padded shards on the
+// handle's stream; the communicator is made at the first gather of a handle from a ncclUniqueId that rank 0 leaves
+// in a file next to `rendezvous`.  RCCL is looked up in the process at run time (a host program of the library need
+// not link it; in a torch process it is torch's copy).  transport 1 moves the records through files on a filesystem
+// every rank sees: no GPU involved, for ranks that share one GPU and for tests.
+namespace {
+
+struct RcclApi {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok() const { return GetUniqueId && CommInitRank && CommDestroy && AllGather && GetErrorString; }
+};
+RcclApi &rccl() {
+  static RcclApi api = [] {
+    RcclApi a;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      a.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);  // a copy the process already has (torch's) comes first
+      if (a.lib) break;
+    }
+    if (!a.lib)
+      for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (a.lib) break;
+      }
+    if (a.lib) {
+      a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.lib, "ncclGetUniqueId");
+      a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.lib, "ncclCommInitRank");
+      a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.lib, "ncclCommDestroy");
+      a.AllGather = (decltype(a.AllGather))dlsym(a.lib, "ncclAllGather");
+      a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.lib, "ncclGetErrorString");
+    }
+    return a;
+  }();
+  return api;
+}
+
+void gather_release(relate_hip_t h) {
+  if (h->comm && rccl().ok()) (void)rccl().CommDestroy(h->comm);
+  h->comm = nullptr;
+  h->dGatherS.release();
+  h->dGatherR.release();
+}
+
+bool write_file_atomically(const std::string &path, const void *data, size_t bytes) {
+  std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+  FILE *f = std::fopen(tmp.c_str(), "wb");
+  if (!f) return false;
+  bool ok = std::fwrite(data, 1, bytes, f) == bytes;
+  ok = (std::fclose(f) == 0) && ok;
+  return ok && std::rename(tmp.c_str(), path.c_str()) == 0;
+}
+// waits until the file is there in full; seconds < 0 waits for ever
+bool read_file_when_ready(const std::string &path, void *data, size_t bytes, double seconds) {
+  auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    struct stat st;
+    if (stat(path.c_str(), &st) == 0 && (size_t)st.st_size == bytes) {
+      FILE *f = std::fopen(path.c_str(), "rb");
+      if (f) {
+        bool ok = std::fread(data, 1, bytes, f) == bytes;
+        std::fclose(f);
+        if (ok) return true;
+      }
+    }
+    if (seconds >= 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
+    usleep(2000);
+  }
+}
+double gather_timeout() {
+  const char *e = getenv("RELATE_GATHER_TIMEOUT");
+  return e ? atof(e) : 1800.0;
+}
+
+}  // namespace
+
+extern "C" int relate_hip_gather(relate_hip_t h, const relate_fit *mine, int64_t P_total, int rank, int nranks,
+                                 const char *rendezvous, int transport, relate_fit *all) {
+  if (P_total < 0 || nranks < 1 || rank < 0 || rank >= nranks || !all || (!mine && P_total > 0))
+    return fail(h, RELATE_E_ARG, "bad arguments");
+  if (transport != 0 && transport != 1) return fail(h, RELATE_E_ARG, "transport: 0 = RCCL, 1 = files");
+  if (transport == 0 && !h) return fail(nullptr, RELATE_E_ARG, "the RCCL gather needs a handle (its GPU and stream)");
+  if (nranks > 1 && (!rendezvous || !*rendezvous))
+    return fail(h, RELATE_E_ARG, "a rendezvous path every rank sees is needed for more than one rank");
+  int64_t b = 0, e = 0;
+  relate_hip_shard(P_total, rank, nranks, &b, &e);
+  const long seq = h ? h->gather_seq++ : 0;
+  const std::string base = std::string(rendezvous ? rendezvous : "") + ".g" + std::to_string(seq);
+  if (transport == 1) {
+    if (!write_file_atomically(base + ".fit." + std::to_string(rank), mine, sizeof(relate_fit) * (size_t)(e - b)))
+      return fail(h, RELATE_E_ARG, "cannot write " + base + ".fit." + std::to_string(rank));
+    for (int r = 0; r < nranks; r++) {
+      int64_t rb = 0, re = 0;
+      relate_hip_shard(P_total, r, nranks, &rb, &re);
+      if (!read_file_when_ready(base + ".fit." + std::to_string(r), all + rb, sizeof(relate_fit) * (size_t)(re - rb),
+                                gather_timeout()))
+        return fail(h, RELATE_E_ARG, "rank " + std::to_string(r) + " did not deliver " + base + ".fit." + std::to_string(r));
+    }
+    return RELATE_OK;
+  }
+  if (set_device(h)) return RELATE_E_HIP;
+  RcclApi &N = rccl();
+  if (!N.ok()) return fail(h, RELATE_E_HIP, std::string("librccl.so not found in the process or on the library path: ") + (dlerror() ? dlerror() : ""));
+#define NCHK(expr)                                                                                    \
+  do {                                                                                                \
+    ncclResult_t r_ = (expr);                                                                         \
+    if (r_ != ncclSuccess) return fail(h, RELATE_E_HIP, std::string(#expr) + ": " + N.GetErrorString(r_)); \
+  } while (0)
+  if (!h->comm || h->comm_rank != rank || h->comm_n != nranks) {
+    if (h->comm) { (void)N.CommDestroy(h->comm); h->comm = nullptr; }
+    ncclUniqueId id;
+    if (rank == 0) {
+      NCHK(N.GetUniqueId(&id));
+      if (nranks > 1 && !write_file_atomically(base + ".id", &id, sizeof(id)))
+        return fail(h, RELATE_E_ARG, "cannot write " + base + ".id");
+    } else if (!read_file_when_ready(base + ".id", &id, sizeof(id), gather_timeout())) {
+      return fail(h, RELATE_E_ARG, "rank 0 did not deliver " + base + ".id");
+    }
+    NCHK(N.CommInitRank(&h->comm, nranks, id, rank));
+    h->comm_rank = rank;
+    h->comm_n = nranks;
+  }
+  // equal counts per rank: shards are padded to the longest one (they differ by at most one record)
+  const size_t per = (size_t)((P_total + nranks - 1) / nranks) * sizeof(relate_fit);
+  HIPCHK(h, h->dGatherS.ensure(per));
+  HIPCHK(h, h->dGatherR.ensure(per * nranks));
+  HIPCHK(h, hipMemsetAsync(h->dGatherS.p, 0, std::max<size_t>(per, 1), h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->dGatherS.p, mine, sizeof(relate_fit) * (size_t)(e - b), hipMemcpyHostToDevice, h->stream));
+  NCHK(N.AllGather(h->dGatherS.p, h->dGatherR.p, per, ncclInt8, h->comm, h->stream));
+  std::vector<unsigned char> host(per * nranks);
+  HIPCHK(h, hipMemcpyAsync(host.data(), h->dGatherR.p, host.size(), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+#undef NCHK
+  for (int r = 0; r < nranks; r++) {
+    int64_t rb = 0, re = 0;
+    relate_hip_shard(P_total, r, nranks, &rb, &re);
+    std::memcpy(all + rb, host.data() + per * r, sizeof(relate_fit) * (size_t)(re - rb));
   }
   return RELATE_OK;
 }
