@@ -53,7 +53,7 @@ SURVEY_BYTES = {"like": 0.5, "decode": 0.5 + 8.0 * 3}
 # density (four fifths of the record groups take the shortest series).  Peak = one FP64
 # instruction per lane per 4 cycles per SIMD at the 2.4 GHz boost clock; under this load the part holds 1.6-1.7 GHz
 # (GRBM_GUI_ACTIVE / 8 / kernel time) and a pure FMA stream measures 28.8e12 lane-FMA/s (tools/ubench/fp64_ops.hip).
-VALU_PER_STEP = {1: 27.8, 3: 55.2}
+VALU_PER_STEP = {1: 28.3, 3: 53.0}
 FP64_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9  # 39.3e12 at the 2.4 GHz boost clock
 
 
@@ -199,10 +199,67 @@ def fit_leg(H, allp, npairs, M):
     res = H.fit(blk)
     dt = time.perf_counter() - t0
     tm = H.timings()
+    st = H.like_stats()
+    # point-steps = (pair, SNP, parameter point) updates of all likelihood launches of the fit, counted by the library;
+    # FP64 instructions per point-step by route from the PMC passes (VALU_PER_STEP); fraction of the 39.3e12 nominal
+    # lane-instructions/s, over the wall-clock of the whole call (host optimiser steps and transfers included)
+    steps = st["sweep_point_steps"] + st["chunked_point_steps"]
+    insts = st["sweep_point_steps"] * VALU_PER_STEP[1] + st["chunked_point_steps"] * VALU_PER_STEP[3]
     return {"pairs": int(npairs), "seconds": dt, "buffer_growth_seconds": t_grow, "pairs_per_s": npairs / dt, "pair_snp_per_s": npairs * M / dt,
             "like_kernel_seconds": tm["like_ms"] / 1e3, "restarts_per_pair": sum(r["timesRun"] for r in res) / npairs,
             "pairs_with_nan": int(sum(r["status"] != 0 for r in res)),
-            "note": "relate_hip_fit, options.all.pair.txt semantics (calcA, timesToRun 8); not part of value"}
+            "lane_steps": steps, "lane_steps_per_s": steps / dt, "fp64_frac": insts / dt / FP64_LANE_OPS_PEAK,
+            "fp64_frac_kernel_time": insts / (tm["like_ms"] / 1e3) / FP64_LANE_OPS_PEAK,
+            "launches": {"sweep": st["sweep_launches"], "chunked": st["chunked_launches"],
+                         "sweep_ms": st["sweep_ms"], "chunked_ms": st["chunked_ms"],
+                         "sweep_lane_steps": st["sweep_point_steps"], "chunked_lane_steps": st["chunked_point_steps"]},
+            "note": "relate_hip_fit, options.all.pair.txt semantics (calcA, timesToRun 8: the 2-parameter mode whose estimates "
+                    "the reference itself does not reproduce across seeds, so its outputs are validated to -logL within 2e-3 only); "
+                    "not part of value"}
+
+
+def opts_linkage():
+    """data/options.linkage.txt after the float parse: 1-parameter mode (k2 fixed at 0, a from k1), back = 50 -- what
+    the manual prescribes for 500k-SNP chips -- and LD pruning at r^2 > 0.1."""
+    f = lambda x: float(np.float32(x))  # noqa: E731
+    return dict(min=f(0.025), epsilon=f(0.01), prune_val=f(0.1), alim0=f(0.001), alim1=f(0.15), fixA_val=f(0.5),
+                fixK_val=0.0, phi=f(0.013), convTol=f(0.1), par=(f(0.3), 0.0, 0.5), back=50, doPrune=1, LD=1, ld_adj=1,
+                double_recom=0, fixA=0, fixK=1, calcA=1, timesToConverge=3, timesToRun=1, doPar=0, seed_mode=0,
+                seed=20240601)
+
+
+def linkage_leg(local, inds, snps, allp, npairs):
+    """Outside the timed region and not part of `value`: config 5's semantics (options.linkage.txt: back = 50, the generic
+    staging route; pruning; one 1-parameter search per pair; decode of the one row the .post file keeps) at config 4's
+    SNP count -- staging, fit and decode of one pair block, each timed on its own."""
+    import relate_amd
+    from relate_amd import synth
+    opt = opts_linkage()
+    geno, pos, chr_, _ = synth.make_dataset(inds, snps, device="cuda:%d" % local)
+    H = relate_amd.Relate(local)
+    t0 = time.perf_counter()
+    M = H.init_globals(geno, pos, chr_, opt)
+    t_pre = time.perf_counter() - t0
+    del geno
+    blk = allp[:npairs]
+    H.bench_like(blk, eval_points(npairs, 1), 1)             # stages the block (generic K4) + one likelihood point
+    stage_ms = H.timings()["stage_ms"]
+    t0 = time.perf_counter()
+    res = H.fit(blk)
+    t_fit = time.perf_counter() - t0
+    par = np.array([(r["a"], r["k2"], r["k1"]) for r in res])
+    t0 = time.perf_counter()
+    H.decode_f32(blk[:min(npairs, 1024)], par[:min(npairs, 1024)], rows=1)
+    t_dec = time.perf_counter() - t0
+    tm = H.timings()
+    out = {"pairs": int(npairs), "snps_after_maf_and_pruning": int(M), "load_precalc_prune_s": t_pre,
+           "stage_ms": stage_ms, "stage_gbs": (24.75 * npairs * M) / (stage_ms * 1e-3) / 1e9 if stage_ms else None,
+           "fit_seconds": t_fit, "fit_pairs_per_s": npairs / t_fit, "fit_like_kernel_seconds": tm["like_ms"] / 1e3,
+           "decode_rows1_pairs": int(min(npairs, 1024)), "decode_rows1_seconds_with_host_copy": t_dec,
+           "pairs_not_ok": int(sum(r["status"] != 0 for r in res)),
+           "note": "options.linkage.txt semantics on the same synthetic matrix; not part of value"}
+    H.close()
+    return out
 
 
 def main():
@@ -216,6 +273,9 @@ def main():
     ap.add_argument("--points", type=int, default=5, help="evaluation points per pair per like launch")
     ap.add_argument("--no-cpu", action="store_true", help="bench line only: no cpu_baseline, no fit leg")
     ap.add_argument("--no-fit", action="store_true")
+    ap.add_argument("--no-baseline", action="store_true", help="skip the CPU baselines only (profiling runs)")
+    ap.add_argument("--no-linkage", action="store_true")
+    ap.add_argument("--linkage-pairs", type=int, default=4096)
     ap.add_argument("--fit-pairs", type=int, default=8192)
     args = ap.parse_args()
 
@@ -306,7 +366,8 @@ def main():
         BYTES = algorithmic_bytes(lc, dc)
         units = P * M
         gbs = {k: BYTES[k] * units / (per[k] * 1e-3) / 1e9 for k in per}
-        dom = max(per, key=per.get)
+        # the dominant kernel of the step among the HBM-bound ones (the likelihood group is FP64-VALU-bound: roofline_fp64)
+        dom = max((k for k in per if k != "like"), key=per.get)
         kernel_name = {"stage": "stage_pairs_win_kernel",
                        "like": "chunk_matrix_kernel<false, false>" if lc > 1 else "like_kernel",
                        "decode_fwd": "chunk_matrix_kernel<false, true>",
@@ -335,7 +396,7 @@ def main():
                          "frac_survey_decode": SURVEY_BYTES["decode"] * units
                                                / ((per["decode_fwd"] + per["decode_bwd"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "bytes_per_pair_snp_step": sum(BYTES.values()),
-                         "note": "dominant = largest share of the step; traffic = HBM bytes per launch from the "
+                         "note": "dominant = the HBM-bound kernel with the largest share of the step (the likelihood kernels, a comparable share, are FP64-VALU-bound: roofline_fp64); traffic = HBM bytes per launch from the "
                                  "committed PMC passes (profiles/pmc_traffic.json), null if they were taken on another "
                                  "configuration.  The likelihood kernels are FP64-VALU-bound by design (two expm1 "
                                  "per lane-step, 5 lanes share one 32 B record): see roofline_fp64"},
@@ -348,9 +409,11 @@ def main():
             "kernels_hbm_frac": {k: v / HBM_PEAK_GBS for k, v in gbs.items()},
             "setup_s": {"synthetic_data": t_gen, "load_precalc": t_pre},
         }
+        if world == 1 and not args.no_cpu and not args.no_linkage:
+            line["linkage_mode"] = linkage_leg(local, args.inds, args.snps, all_pairs, min(args.linkage_pairs, len(all_pairs)))
         if world == 1 and not args.no_cpu and not args.no_fit:
             line["fit"] = fit_leg(H, mine, min(args.fit_pairs, len(mine)), M)
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and not args.no_baseline:
             line["cpu_baseline"] = cpu_baseline(H, opt, E)
             line["cpu_baseline_all_cores"] = cpu_baseline_threads(H, opt, E)
         print(json.dumps(line))

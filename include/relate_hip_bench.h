@@ -13,6 +13,10 @@ extern "C" {
 /* Device time in ms of the kernels launched by the last like / decode / pair_emissions-stage call,
  * measured with hipEvents on the library's stream: out = {stage_ms, like_ms, decode_fwd_ms, decode_bwd_ms}. */
 int relate_hip_last_timings(relate_hip_t h, double *out4);
+/* The likelihood launches of the last relate_hip_fit: out = {point-steps of launches that sweep every point once (single
+ * and two-sided sweeps), point-steps of launches cut along the SNP axis (three-row chunk products), their kernel ms,
+ * their counts}; a point-step = one (pair, SNP, parameter point) update. */
+int relate_hip_last_like_stats(relate_hip_t h, double *out6);
 /* Number of SNP-axis chunks the last like / decode launch was cut into (1 = single sweep; > 1 adds the chunk-product
  * pass): needed to state the algorithmic bytes of a launch. */
 int relate_hip_last_chunks(relate_hip_t h, int *like_chunks, int *decode_chunks);

@@ -115,6 +115,7 @@ def load_library():
     L.relate_hip_shard.restype = None
     L.relate_hip_last_timings.argtypes = [vp, dp]
     L.relate_hip_last_chunks.argtypes = [vp, ip, ip]
+    L.relate_hip_last_like_stats.argtypes = [vp, dp]
     fpt = C.POINTER(C.c_float)
     L.relate_hip_linkage.argtypes = [vp, fpt, C.c_int, C.c_int, fpt, fpt, ip, C.c_int, C.POINTER(LinkageOpts), fpt, fpt,
                                      fpt, fpt, C.POINTER(LinkageResult)]
@@ -386,6 +387,13 @@ class Relate:
         t = np.zeros(4)
         self.L.relate_hip_last_timings(self.h, t.ctypes.data_as(dp))
         return dict(stage_ms=t[0], like_ms=t[1], decode_fwd_ms=t[2], decode_bwd_ms=t[3])
+
+    def like_stats(self):
+        """Likelihood launches of the last fit: point-steps, kernel ms and launch counts by route (sweep, chunked)."""
+        s = np.zeros(6)
+        self.L.relate_hip_last_like_stats(self.h, s.ctypes.data_as(dp))
+        return dict(sweep_point_steps=s[0], chunked_point_steps=s[1], sweep_ms=s[2], chunked_ms=s[3],
+                    sweep_launches=int(s[4]), chunked_launches=int(s[5]))
 
     def last_chunks(self):
         a, b = C.c_int(0), C.c_int(0)

@@ -150,6 +150,7 @@ struct relate_hip_ctx {
   void *bounce[2] = {nullptr, nullptr};  // pinned staging of results on their way to pageable caller memory
   hipEvent_t bounceEv[2] = {nullptr, nullptr};
   double timings[4] = {0, 0, 0, 0};
+  double like_stats[6] = {0, 0, 0, 0, 0, 0};  // relate_hip_last_like_stats
   int last_chunks[2] = {1, 1};  // SNP-axis chunks of the last like / decode launch
   long slots_like = 2048, slots_decode = 6144;  // resident waves of the chunked sweeps (set at create)
   ncclComm_t comm = nullptr;  // relate_hip_gather: one communicator per handle, made at the first gather
@@ -589,6 +590,12 @@ int like_wait(relate_hip_t h, LaneBufs &B) {
   float ms = 0;
   HIPCHK(h, hipEventElapsedTime(&ms, B.e0, B.e1));
   h->timings[1] += ms;
+  {
+    const int k = B.chunks > 1 ? 1 : 0;  // 0: one or two sweeps per point, 1: cut along the SNP axis (three-row products)
+    h->like_stats[k] += (double)B.nl * h->M;
+    h->like_stats[2 + k] += ms;
+    h->like_stats[4 + k] += 1;
+  }
   if (getenv("RELATE_FIT_TRACE"))
     std::fprintf(stderr, "like launch: %d lanes, %d chunks, %.3f ms\n", B.nl, B.chunks, ms);
   return 0;
@@ -1613,6 +1620,7 @@ int relate_hip_fit(relate_hip_t h, const int32_t *pairs, int P, const double *st
   if (rc) return rc;
   if (!pairs || !out || P < 0) return fail(h, RELATE_E_ARG, "bad arguments");
   h->timings[1] = 0;
+  for (double &v : h->like_stats) v = 0;
   if (conv_out) std::memset(conv_out, 0, sizeof(double) * (size_t)P * std::max(1, h->o.timesToRun) * 4);
   size_t lim = pair_block_limit(h, {need_rec(h)});
   for (long b0 = 0; b0 < P; b0 += (long)lim) {
@@ -1742,6 +1750,12 @@ void relate_hip_shard(int64_t P, int rank, int nranks, int64_t *begin, int64_t *
 int relate_hip_last_timings(relate_hip_t h, double *out4) {
   if (!h || !out4) return RELATE_E_ARG;
   for (int i = 0; i < 4; i++) out4[i] = h->timings[i];
+  return RELATE_OK;
+}
+
+int relate_hip_last_like_stats(relate_hip_t h, double *out6) {
+  if (!h || !out6) return RELATE_E_ARG;
+  for (int i = 0; i < 6; i++) out6[i] = h->like_stats[i];
   return RELATE_OK;
 }
 
