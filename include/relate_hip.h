@@ -213,6 +213,18 @@ int relate_hip_linkage(relate_hip_t h, const float *post, int R, int M, const fl
                        int n_ind, const relate_linkage_opts *o, float *stat, float *xmax, float *covar, float *post_out,
                        relate_linkage_result *res);
 
+/* The same statistic with the posterior rows decoded on the spot and never leaving HBM: decode (IBD0 row as float, the
+ * row the linkage pipeline's .post file holds: fixK2 = 1 with value 0, src/relateHMM.cpp:3771-3782) of the R pairs at
+ * params (R x 3: a, k2, k1 -- the estimates of relate_hip_fit), block by block into one R x M matrix on the device,
+ * then uber_main's steps on it (src/HMMtest.txt:1195-1367).  Replaces the hand-off through the .post file between the
+ * two programs.  digits = 4: every posterior is first rounded to the 4 significant digits that file carries
+ * (POSTPRECISION, src/conf.h:8), so the statistic is the one HMMtest computes from the reference's output; digits = 0:
+ * float posteriors as decoded.  pos NULL = the stripped positions of the handle's data set as floats.  Pairs in the
+ * all-pairs order of the n_ind individuals of cc; other arguments and outputs as relate_hip_linkage (M = SNPs kept). */
+int relate_hip_linkage_pairs(relate_hip_t h, const int32_t *pairs, int R, const double *params, int digits,
+                             const float *pos, const float *K, const int *cc, int n_ind, const relate_linkage_opts *o,
+                             float *stat, float *xmax, float *covar, float *post_out, relate_linkage_result *res);
+
 #ifdef __cplusplus
 }
 #endif

@@ -119,6 +119,8 @@ def load_library():
     fpt = C.POINTER(C.c_float)
     L.relate_hip_linkage.argtypes = [vp, fpt, C.c_int, C.c_int, fpt, fpt, ip, C.c_int, C.POINTER(LinkageOpts), fpt, fpt,
                                      fpt, fpt, C.POINTER(LinkageResult)]
+    L.relate_hip_linkage_pairs.argtypes = [vp, i32p, C.c_int, dp, C.c_int, fpt, fpt, ip, C.c_int, C.POINTER(LinkageOpts),
+                                           fpt, fpt, fpt, fpt, C.POINTER(LinkageResult)]
     L.relate_hip_bench_like.argtypes = [vp, i32p, C.c_int, dp, C.c_int, C.c_int, dp]
     L.relate_hip_bench_decode.argtypes = [vp, i32p, C.c_int, dp, C.c_int, dp, dp]
     _lib = L
@@ -379,6 +381,29 @@ class Relate:
         f = lambda a: None if a is None else a.ctypes.data_as(fpt)  # noqa: E731
         self._chk(self.L.relate_hip_linkage(self.h, f(p), R, M, f(ps), f(k), c.ctypes.data_as(ip), len(c), C.byref(o),
                                             f(stat), f(xmax), f(cov), f(pout), C.byref(res)))
+        return dict(stat=stat, xmax=xmax, cov=cov, post=pout, pmaxsim=res.pmaxsim, psim_over_nsim=res.psim_over_nsim,
+                    psigsim=res.psigsim, n_case_pairs=res.n_case_pairs, n_control_pairs=res.n_control_pairs)
+
+    def linkage_pairs(self, pairs, params, cc, digits=4, pos=None, K=None, isK0=0, nsim=10, ccAll=0, sig=0.05, infer=1,
+                      seed=1, want_cov=False, want_post=False):
+        """Decode (IBD0 row) + HMMtest without the posterior rows leaving the device (relate_hip_linkage_pairs)."""
+        fpt = C.POINTER(C.c_float)
+        p, pp = self._pairs(pairs)
+        par = np.ascontiguousarray(params, dtype=np.float64).reshape(len(p), 3)
+        R, M = len(p), self.M
+        c = np.ascontiguousarray(cc, dtype=np.int32)
+        ps = None if pos is None else np.ascontiguousarray(pos, dtype=np.float32)
+        k = None if K is None else np.ascontiguousarray(K, dtype=np.float32)
+        o = LinkageOpts(nsim, ccAll, infer, isK0, sig, seed)
+        stat = np.zeros(M, dtype=np.float32)
+        xmax = np.zeros(nsim, dtype=np.float32)
+        cov = np.zeros((R, R), dtype=np.float32) if want_cov else None
+        pout = np.zeros((R, M), dtype=np.float32) if want_post else None
+        res = LinkageResult()
+        f = lambda a: None if a is None else a.ctypes.data_as(fpt)  # noqa: E731
+        self._chk(self.L.relate_hip_linkage_pairs(self.h, pp, R, par.ctypes.data_as(dp), digits, f(ps), f(k),
+                                                  c.ctypes.data_as(ip), len(c), C.byref(o), f(stat), f(xmax), f(cov),
+                                                  f(pout), C.byref(res)))
         return dict(stat=stat, xmax=xmax, cov=cov, post=pout, pmaxsim=res.pmaxsim, psim_over_nsim=res.psim_over_nsim,
                     psigsim=res.psigsim, n_case_pairs=res.n_case_pairs, n_control_pairs=res.n_control_pairs)
 

@@ -910,6 +910,21 @@ __device__ inline void dec_tile(const LaneC &C, const Rec (&R)[kTile], double f0
   }
 }
 
+// A posterior as the reference's .post text carries it: "%.4g" (POSTPRECISION, src/conf.h:8), i.e. the double rounded
+// to four significant decimal digits (the caller then rounds that once to float, as a float reader of the file does).
+// -1 (dropped SNP), 0 and NaN pass through.  The scaled value is exact enough that only values within ~1e-12 relative
+// of a rounding boundary could round the other way than printf does.
+__device__ inline double round_sig4(double x) {
+  if (!(x > 0)) return x;
+  int e = (int)floor(log10(x));
+  double s = x * pow(10.0, (double)(3 - e));
+  if (s < 1000.0) { e--; s = x * pow(10.0, (double)(3 - e)); }
+  else if (s >= 10000.0) { e++; s = x * pow(10.0, (double)(3 - e)); }
+  double r = rint(s);
+  if (r >= 10000.0) { r = 1000.0; e++; }
+  return (3 - e >= 0) ? r / pow(10.0, (double)(3 - e)) : r * pow(10.0, (double)(e - 3));
+}
+
 // Backward sweep inside one chunk + posterior.  post is P x 3 x M (pair-major, as the host writer wants it): row0
 // IBD2, row1 IBD1, row2 IBD0 (decodek2, :1133-1137); -1 where the SNP is dropped (.post writer, :126-133).
 // posterior_x(s) = fwd_x(s) bwd_x(s) / sum_y fwd_y(s) bwd_y(s): every scale factor cancels.
@@ -922,7 +937,7 @@ template <bool DR, typename OutT>
 __global__ void __launch_bounds__(kBwdThreads)
 decode_bwd_kernel(const double *__restrict__ rec, int M, int P, int RP, int col0, const double *__restrict__ params,
                   int nlp, int chunk_len, const double *__restrict__ astart, const double *__restrict__ bend,
-                  TileCkpt ck, OutT *__restrict__ post, int rows) {
+                  TileCkpt ck, OutT *__restrict__ post, int rows, int sig4) {  // sig4: float rows rounded as the .post text
   __shared__ double tile[3][kBwdThreads][kTilePad];
   int bpc = (P + kBwdThreads - 1) / kBwdThreads;
   int c = blockIdx.x / bpc;
@@ -973,7 +988,8 @@ decode_bwd_kernel(const double *__restrict__ rec, int M, int P, int RP, int col0
         if (s < te && pp < P) post[((size_t)pp * 3 + r) * M + s] = tile[r][pr][e];
       } else {
         int rr = 2 - r;
-        if (s < te && pp < P && rr < rows) post[((size_t)pp * rows + rr) * M + s] = (OutT)tile[r][pr][e];
+        if (s < te && pp < P && rr < rows)
+          post[((size_t)pp * rows + rr) * M + s] = (OutT)(sig4 ? round_sig4(tile[r][pr][e]) : tile[r][pr][e]);
       }
     }
     __syncthreads();

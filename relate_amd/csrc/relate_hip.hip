@@ -1033,7 +1033,7 @@ int copy_to_host(relate_hip_t h, void *dst, const void *src, size_t bytes) {
 
 // K6 launches for pairs [p0, p0 + P) of the staged block with their params already in dParams; posteriors left in dPost
 // (f32_rows: 0 = doubles, P x 3 x M; 1..3 = floats, P x f32_rows x M in writer order, in the same buffer)
-int launch_decode(relate_hip_t h, int p0, int P, int f32_rows = 0) {
+int launch_decode(relate_hip_t h, int p0, int P, int f32_rows = 0, int sig4 = 0) {
   const int M = h->M;
   int nchunk, clen;
   pick_chunks(M, P, h->single_sweep_lanes, 256, h->slots_decode, 1, &nchunk, &clen);
@@ -1073,7 +1073,7 @@ int launch_decode(relate_hip_t h, int p0, int P, int f32_rows = 0) {
   dim3 bgrid((unsigned)((size_t)((P + kBwdThreads - 1) / kBwdThreads) * nchunk));
 #define LAUNCH_BWD(DRV, T, OUT, ROWS)                                                                              \
   hipLaunchKernelGGL((decode_bwd_kernel<DRV, T>), bgrid, dim3(kBwdThreads), 0, h->stream, rec, M, P, RP, p0,         \
-                     h->dParams.p, nlp, clen, astart, bend, ck, OUT, ROWS)
+                     h->dParams.p, nlp, clen, astart, bend, ck, OUT, ROWS, sig4)
   if (f32_rows) {
     float *pf = reinterpret_cast<float *>(h->dPost.p);
     if (dr) LAUNCH_BWD(true, float, pf, f32_rows);
@@ -1091,14 +1091,14 @@ int launch_decode(relate_hip_t h, int p0, int P, int f32_rows = 0) {
 // Decode (and Viterbi) of pairs [p0, p0 + P) of the staged block; `pairs` = those P pairs (needed to stage the full
 // format when a path is wanted).
 int decode_block(relate_hip_t h, const int32_t *pairs, int p0, int P, const double *params, double *post, int8_t *path,
-                 int *nsnp_out, bool copy_back, float *post32 = nullptr, int f32_rows = 0) {
+                 int *nsnp_out, bool copy_back, float *post32 = nullptr, int f32_rows = 0, int sig4 = 0) {
   const int M = h->M;
   HIPCHK(h, h->dParams.ensure((size_t)3 * P));
   HIPCHK(h, hipMemcpyAsync(h->dParams.p, params, sizeof(double) * 3 * P, hipMemcpyHostToDevice, h->stream));
   if (nsnp_out) std::memcpy(nsnp_out, h->h_nsnp.data() + p0, sizeof(int) * P);  // counted by the staging kernel
-  if (post || post32 || !copy_back) {
-    HIPCHK(h, h->dPost.ensure(post32 ? ((size_t)f32_rows * M * P + 1) / 2 : (size_t)3 * M * P));
-    int rc = launch_decode(h, p0, P, post32 ? f32_rows : 0);
+  if (post || post32 || !copy_back) {  // (f32_rows > 0 without post32: float rows left on the device)
+    HIPCHK(h, h->dPost.ensure(f32_rows ? ((size_t)f32_rows * M * P + 1) / 2 : (size_t)3 * M * P));
+    int rc = launch_decode(h, p0, P, f32_rows, sig4);
     if (rc) return rc;
     if (copy_back && post) {
       rc = copy_to_host(h, post, h->dPost.p, sizeof(double) * 3 * M * P);
@@ -1864,22 +1864,22 @@ void lk_perm_codes(int n, int n1, int seed, uint8_t *code) {
 
 }  // namespace
 
-extern "C" int relate_hip_linkage(relate_hip_t h, const float *post, int R, int M, const float *pos, const float *K,
-                                  const int *cc, int n_ind, const relate_linkage_opts *o, float *stat, float *xmax,
-                                  float *covar, float *post_out, relate_linkage_result *res) {
-  if (!h) return fail(nullptr, RELATE_E_ARG, "null handle");
-  if (!post || !cc || !o || R < 1 || M < 2 || n_ind < 2 || o->nsim < 1) return fail(h, RELATE_E_ARG, "bad arguments");
+namespace {
+// HMMtest on a posterior matrix that is already in device memory (dPp: R x M floats, overwritten by the inference of
+// missing values when infer = 1)
+int linkage_on_device(relate_hip_t h, float *dPp, int R, int M, const float *pos, const float *K, const int *cc, int n_ind,
+                      const relate_linkage_opts *o, float *stat, float *xmax, float *covar, float *post_out,
+                      relate_linkage_result *res) {
   if ((long)n_ind * (n_ind - 1) / 2 != R)
     return fail(h, RELATE_E_ARG, "the posterior file must hold one row per pair of the individuals in the -D file (" +
                                      std::to_string((long)n_ind * (n_ind - 1) / 2) + " rows, got " + std::to_string(R) + ")");
   if (o->infer == 1 && !pos) return fail(h, RELATE_E_ARG, "Position file required for removing missing");
-  if (set_device(h)) return RELATE_E_HIP;
   hipStream_t st = h->stream;
   const int nsim = o->nsim;
-  DBuf<float> dP, dPos, dK, dCov, dU1, dU0, dScal, dX0, dXmax;
+  DBuf<float> dPos, dK, dCov, dU1, dU0, dScal, dX0, dXmax;
   DBuf<int> dPsim;
   auto cleanup = [&]() {
-    dP.release(); dPos.release(); dK.release(); dCov.release(); dU1.release(); dU0.release(); dScal.release();
+    dPos.release(); dK.release(); dCov.release(); dU1.release(); dU0.release(); dScal.release();
     dX0.release(); dXmax.release(); dPsim.release();
   };
 #define LCHK(expr)                                                                              \
@@ -1891,13 +1891,11 @@ extern "C" int relate_hip_linkage(relate_hip_t h, const float *post, int R, int 
                   std::string(#expr) + ": " + hipGetErrorString(e_));                           \
     }                                                                                           \
   } while (0)
-  LCHK(dP.ensure((size_t)R * M));
-  LCHK(hipMemcpyAsync(dP.p, post, sizeof(float) * (size_t)R * M, hipMemcpyHostToDevice, st));
   int missing = 1;
   if (o->infer == 1) {
     LCHK(dPos.ensure(M));
     LCHK(hipMemcpyAsync(dPos.p, pos, sizeof(float) * M, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(lk_fix_missing_kernel, dim3(blocks_for(R, 64)), dim3(64), 0, st, dP.p, R, M, dPos.p);
+    hipLaunchKernelGGL(lk_fix_missing_kernel, dim3(blocks_for(R, 64)), dim3(64), 0, st, dPp, R, M, dPos.p);
     LCHK(hipGetLastError());
     missing = 0;
   }
@@ -1908,13 +1906,13 @@ extern "C" int relate_hip_linkage(relate_hip_t h, const float *post, int R, int 
     LCHK(hipMemcpyAsync(dK.p, k.data(), sizeof(float) * R, hipMemcpyHostToDevice, st));
     LCHK(hipStreamSynchronize(st));
   } else {
-    hipLaunchKernelGGL(lk_row_mean_kernel, dim3(blocks_for(R, 64)), dim3(64), 0, st, dP.p, R, M, missing, dK.p);
+    hipLaunchKernelGGL(lk_row_mean_kernel, dim3(blocks_for(R, 64)), dim3(64), 0, st, dPp, R, M, missing, dK.p);
     LCHK(hipGetLastError());
   }
   LCHK(dCov.ensure((size_t)R * R));
   {
     unsigned g = (unsigned)((R + kCovT - 1) / kCovT);
-    hipLaunchKernelGGL(lk_covar_kernel, dim3(g, g), dim3(256), 0, st, dP.p, dK.p, R, M, missing, dCov.p);
+    hipLaunchKernelGGL(lk_covar_kernel, dim3(g, g), dim3(256), 0, st, dPp, dK.p, R, M, missing, dCov.p);
     LCHK(hipGetLastError());
   }
   // Case lists and permutations (host: integer bookkeeping on the glibc rand() / LCG streams).  The reference keeps
@@ -1971,7 +1969,7 @@ extern "C" int relate_hip_linkage(relate_hip_t h, const float *post, int R, int 
   for (int b0 = 0; b0 < nsim; b0 += batch) {
     int nb = std::min(batch, nsim - b0);
     const int *a = dLa.p + (size_t)b0 * LA, *n = dLn.p + (size_t)b0 * LN;
-    hipLaunchKernelGGL(lk_col_means_kernel, dim3(blocks_for(M, 256), nb), dim3(256), 0, st, dP.p, M, a, LA, n, LN, missing,
+    hipLaunchKernelGGL(lk_col_means_kernel, dim3(blocks_for(M, 256), nb), dim3(256), 0, st, dPp, M, a, LA, n, LN, missing,
                        dU1.p, dU0.p);
     L2CHK(hipGetLastError());
     hipLaunchKernelGGL(lk_perm_scalars_kernel, dim3(blocks_for(nb, 64)), dim3(64), 0, st, dK.p, dCov.p, R, a, LA, n, LN, nb,
@@ -1991,7 +1989,7 @@ extern "C" int relate_hip_linkage(relate_hip_t h, const float *post, int R, int 
   L2CHK(hipMemcpyAsync(hps.data(), dPsim.p, sizeof(int) * M, hipMemcpyDeviceToHost, st));
   if (stat) L2CHK(hipMemcpyAsync(stat, dX0.p, sizeof(float) * M, hipMemcpyDeviceToHost, st));
   if (covar) L2CHK(hipMemcpyAsync(covar, dCov.p, sizeof(float) * (size_t)R * R, hipMemcpyDeviceToHost, st));
-  if (post_out) L2CHK(hipMemcpyAsync(post_out, dP.p, sizeof(float) * (size_t)R * M, hipMemcpyDeviceToHost, st));
+  if (post_out) L2CHK(hipMemcpyAsync(post_out, dPp, sizeof(float) * (size_t)R * M, hipMemcpyDeviceToHost, st));
   L2CHK(hipStreamSynchronize(st));
   cleanup2();
 #undef LCHK
@@ -2013,6 +2011,68 @@ extern "C" int relate_hip_linkage(relate_hip_t h, const float *post, int R, int 
     res->n_control_pairs = n_ctrl;
   }
   return RELATE_OK;
+}
+}  // namespace
+
+extern "C" int relate_hip_linkage(relate_hip_t h, const float *post, int R, int M, const float *pos, const float *K,
+                                  const int *cc, int n_ind, const relate_linkage_opts *o, float *stat, float *xmax,
+                                  float *covar, float *post_out, relate_linkage_result *res) {
+  if (!h) return fail(nullptr, RELATE_E_ARG, "null handle");
+  if (!post || !cc || !o || R < 1 || M < 2 || n_ind < 2 || o->nsim < 1) return fail(h, RELATE_E_ARG, "bad arguments");
+  if (set_device(h)) return RELATE_E_HIP;
+  DBuf<float> dP;
+  hipError_t e = dP.ensure((size_t)R * M);
+  if (e == hipSuccess) e = hipMemcpyAsync(dP.p, post, sizeof(float) * (size_t)R * M, hipMemcpyHostToDevice, h->stream);
+  if (e != hipSuccess) {
+    dP.release();
+    return fail(h, e == hipErrorOutOfMemory ? RELATE_E_NOMEM : RELATE_E_HIP, std::string("posterior matrix: ") + hipGetErrorString(e));
+  }
+  int rc = linkage_on_device(h, dP.p, R, M, pos, K, cc, n_ind, o, stat, xmax, covar, post_out, res);
+  dP.release();
+  return rc;
+}
+
+// Decode -> linkage without leaving HBM: the IBD0 posterior row of every pair (the row the .post file of the linkage
+// pipeline holds, src/relateHMM.cpp:3771-3782 with fixK2 = 1, value 0) is decoded block by block into one R x M float
+// matrix on the device and handed to the linkage kernels.  digits = 4 rounds every value to the four significant
+// digits the reference's .post text carries (POSTPRECISION, src/conf.h:8), so that the statistic is the one HMMtest
+// computes from the file; digits = 0 keeps the float posteriors.
+extern "C" int relate_hip_linkage_pairs(relate_hip_t h, const int32_t *pairs, int R, const double *params, int digits,
+                                        const float *pos, const float *K, const int *cc, int n_ind,
+                                        const relate_linkage_opts *o, float *stat, float *xmax, float *covar,
+                                        float *post_out, relate_linkage_result *res) {
+  int rc = require_ready(h);
+  if (rc) return rc;
+  if (!pairs || !params || !cc || !o || R < 1 || n_ind < 2 || o->nsim < 1 || (digits != 0 && digits != 4))
+    return fail(h, RELATE_E_ARG, "bad arguments");
+  const int M = h->M;
+  DBuf<float> dAll;
+  HIPCHK(h, dAll.ensure((size_t)R * M));
+  h->timings[2] = h->timings[3] = 0;
+  size_t lim = pair_block_limit(h, {need_rec(h), need_post(h, 4.0), need_ckpt(h)});
+  for (long b0 = 0; b0 < R && !rc; b0 += (long)lim) {
+    int pb = (int)std::min<long>((long)lim, R - b0);
+    rc = stage_block(h, pairs + 2 * b0, pb);
+    if (!rc)
+      rc = decode_block(h, pairs + 2 * b0, 0, pb, params + 3 * b0, nullptr, nullptr, nullptr, false, nullptr, 1,
+                        digits == 4 ? 1 : 0);
+    if (!rc) {
+      hipError_t e = hipMemcpyAsync(dAll.p + (size_t)b0 * M, h->dPost.p, sizeof(float) * (size_t)pb * M,
+                                    hipMemcpyDeviceToDevice, h->stream);
+      if (e != hipSuccess) rc = fail(h, RELATE_E_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+    }
+  }
+  if (!rc) {
+    std::vector<float> fpos;
+    if (!pos) {  // the stripped positions, as a float reader of stripped.pos sees them
+      fpos.resize(M);
+      for (int s = 0; s < M; s++) fpos[s] = (float)h->h_pos[s];
+      pos = fpos.data();
+    }
+    rc = linkage_on_device(h, dAll.p, R, M, pos, K, cc, n_ind, o, stat, xmax, covar, post_out, res);
+  }
+  dAll.release();
+  return rc;
 }
 
 // ---- multi-GPU: the path's one exchange -------------------------------------------------------------------------

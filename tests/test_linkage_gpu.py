@@ -62,3 +62,48 @@ def test_linkage_rejects_inconsistent_inputs(gpu):
         gpu.linkage(post, np.array([0, 1, 0, 1], dtype=np.int32), infer=0)       # 4 individuals = 6 pairs, not 10
     with pytest.raises(relate_amd.RelateError):
         gpu.linkage(post, np.array([0, 1, 0, 1, 1], dtype=np.int32), infer=1)    # infer needs positions
+
+
+def test_decode_to_linkage_on_the_device_equals_the_route_through_the_post_text(gpu):
+    """relate_hip_linkage_pairs (decode + HMMtest, posterior rows never leave HBM) against the route the reference's
+    pipeline takes on the same estimates: decode to the host, the .post text (write_dMatrix_to_file's %.4g, through
+    relate_format_post_rows), the text read back as floats, relate_hip_linkage.  Config 5: dat_small, options.linkage.txt,
+    the 20 keep-list individuals and their case/control file.  digits = 4 rounds the double posteriors on the device as
+    the text does, so the posterior matrix after inference, the statistic and the permutation maxima are the file
+    route's bit for bit; digits = 0 differs by the rounding of the text, < 1e-3."""
+    import os
+    import pathcheck as pc
+    import refload
+    import relate_amd
+    g, pos, chr_ = pc.dataset("dat_small")
+    opt = dict(pc.options("options.linkage.txt"), seed=4242, seed_mode=0)
+    M = gpu.init_globals(g, pos, chr_, opt)
+    pairs = [tuple(int(v) for v in p) for p in refload.keep_pairs(os.path.join(refload.DATA, "dat_small.keep"))]
+    cc = np.array([int(v) for v in open(os.path.join(refload.DATA, "dat_small.cc")).read().split()], dtype=np.int32)
+    assert len(pairs) == 190 and len(cc) == 20
+    res = gpu.fit(pairs)
+    par = np.array([(r["a"], r["k2"], r["k1"]) for r in res])
+    _, spos, _ = gpu.stripped()
+    fpos = spos.astype(np.float32)
+    # file route
+    post, _, _ = gpu.decode(pairs, par)
+    import io as _io
+    from relate_amd import io as rio
+    buf = _io.BytesIO()
+    rio.write_post_block(buf, post, True)       # one row per pair (fixK2 = 1, value 0): the IBD0 posteriors
+    text = np.array([[float(v) for v in r.split(b"\t") if v.strip()] for r in buf.getvalue().splitlines()],
+                    dtype=np.float32)
+    assert text.shape == (190, M)
+    kw = dict(nsim=200, ccAll=0, infer=1, seed=7)
+    want = gpu.linkage(text, cc, pos=fpos, want_post=True, **kw)
+    # device route
+    got = gpu.linkage_pairs(pairs, par, cc, digits=4, pos=fpos, want_post=True, **kw)
+    assert np.array_equal(got["post"], want["post"])
+    assert np.array_equal(got["stat"], want["stat"]) and np.array_equal(got["xmax"], want["xmax"])
+    assert (got["n_case_pairs"], got["n_control_pairs"]) == (want["n_case_pairs"], want["n_control_pairs"])
+    assert (got["pmaxsim"], got["psim_over_nsim"], got["psigsim"]) == (want["pmaxsim"], want["psim_over_nsim"],
+                                                                      want["psigsim"])
+    raw = gpu.linkage_pairs(pairs, par, cc, digits=0, want_post=True, **kw)     # positions from the handle
+    np.testing.assert_allclose(raw["stat"], want["stat"], rtol=2e-2, atol=2e-3)
+    ok = want["post"] != 0
+    np.testing.assert_allclose(raw["post"][ok], want["post"][ok], rtol=1e-3, atol=1e-7)
