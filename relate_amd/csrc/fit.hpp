@@ -168,10 +168,10 @@ class FindMax {
   int npts = 0;
   double pts[7][3];
 
-  void begin(int n_, const double *x0, const double *lo, const double *hi) {
+  void begin(int n_, const double *x0, const double *lo, const double *hi, double *slab = nullptr) {
     n = n_;
     done = false;
-    opt.init(n, x0, lo, hi);
+    opt.init(n, x0, lo, hi, slab);
     // the reference evaluates fun/dfun once at the unprojected start before the first setulb_ call
     // (src/bfgs.c:165-166); those values are overwritten by the FG_START request and are not needed.
     advance();
@@ -251,10 +251,14 @@ struct MultiStart {
   bool finished = false;
   double best[4] = {0, 0, 0, 0};
 
-  int want_to_launch() const {  // how many more runs to start now
+  int first_wave() const { return timesToConverge < timesToRun ? (timesToConverge > 0 ? timesToConverge : 1) : timesToRun; }
+  // how many more runs to start now.  eager: every remaining run at once, without waiting for the wave in flight (the
+  // caller has seen that first waves rarely settle a pair; runs beyond the stopping point are dropped unseen as ever)
+  int want_to_launch(bool eager = false) const {
     if (finished) return 0;
+    if (eager) return timesToRun - launched;
     if (launched > consumed) return 0;  // a wave is still in flight
-    if (launched == 0) return timesToConverge < timesToRun ? (timesToConverge > 0 ? timesToConverge : 1) : timesToRun;
+    if (launched == 0) return first_wave();
     int need = timesToConverge - conv;
     if (need < 1) need = 1;
     int room = timesToRun - launched;

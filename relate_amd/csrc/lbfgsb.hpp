@@ -30,13 +30,27 @@ class Lbfgsb {
   double factr = 1.0e6, pgtol = 1.0e-4;  // FACTR, PGTOL (src/bfgs.h:45-46)
   int iter = 0, nfgv = 0;
 
-  void init(int n_, const double *x0, const double *l, const double *u) {
+  // Work matrices: ws, wy (n x m), sy, ss, wt (m x m), wn, snd (2m x 2m), one after the other in a slab of kSlab doubles.
+  // A caller that keeps thousands of states passes the slab (any contents; recycled from a finished run or fresh from
+  // an arena of its own) -- the matrices are 80 KB per state and, allocated one by one, cost a page fault per 4 KB;
+  // without one the state owns its storage.
+  static constexpr size_t kSlab = (size_t)2 * kMaxN * kM + 3 * kM * kM + 8 * kM * kM;
+  Lbfgsb() = default;
+  Lbfgsb(const Lbfgsb &) = delete;
+  Lbfgsb &operator=(const Lbfgsb &) = delete;
+
+  void init(int n_, const double *x0, const double *l, const double *u, double *slab = nullptr) {
     n = n_;
     for (int i = 0; i < n; i++) { x[i] = x0[i]; lo[i] = l[i]; hi[i] = u[i]; nbd[i] = 2; g[i] = 0; }
     started_ = false;
-    ws_.assign((size_t)n * kM, 0); wy_.assign((size_t)n * kM, 0);
-    sy_.assign((size_t)kM * kM, 0); ss_.assign((size_t)kM * kM, 0); wt_.assign((size_t)kM * kM, 0);
-    wn_.clear(); snd_.clear();  // 2m x 2m each; allocated on first use
+    if (!slab) {
+      own_.resize(kSlab);
+      slab = own_.data();
+    }
+    ws_ = slab; wy_ = ws_ + kMaxN * kM; sy_ = wy_ + kMaxN * kM; ss_ = sy_ + kM * kM; wt_ = ss_ + kM * kM;
+    wn_ = wt_ + kM * kM; snd_ = wn_ + 4 * kM * kM;
+    std::memset(slab, 0, sizeof(double) * (size_t)(wn_ - slab));
+    wn_ready_ = false;  // 2m x 2m each: cleared on first use
     std::memset(wa_, 0, sizeof(wa_));
   }
 
@@ -62,7 +76,9 @@ class Lbfgsb {
   double ginit_, gtest_, gx_, gy_, finit_, fx_, fy_, stx_, sty_, stmin_, stmax_, width_, width1_;
   enum LsTask { LS_START, LS_FG, LS_CONV, LS_WARN, LS_ERROR } lstask_ = LS_START;
 
-  std::vector<double> ws_, wy_, sy_, ss_, wt_, wn_, snd_;
+  std::vector<double> own_;
+  double *ws_ = nullptr, *wy_ = nullptr, *sy_ = nullptr, *ss_ = nullptr, *wt_ = nullptr, *wn_ = nullptr, *snd_ = nullptr;
+  bool wn_ready_ = false;
   double z_[kMaxN + 1], r_[kMaxN + 1], d_[kMaxN + 1], t_[kMaxN + 1], xs_[kMaxN + 1];
   double wa_[8 * kM + 1];
   int index_[kMaxN + 1], iwhere_[kMaxN + 1], indx2_[kMaxN + 1];
@@ -184,9 +200,9 @@ class Lbfgsb {
       for (int k = 1; k <= i - 1; k++) sum += SY(i, k) * V(k) / SY(k, k);
       P(i2) = V(i2) + sum;
     }
-    if (dtrsl(wt_.data(), kM, col, &P(col + 1), 11)) return 1;
+    if (dtrsl(wt_, kM, col, &P(col + 1), 11)) return 1;
     for (int i = 1; i <= col; i++) P(i) = V(i) / std::sqrt(SY(i, i));
-    if (dtrsl(wt_.data(), kM, col, &P(col + 1), 1)) return 1;
+    if (dtrsl(wt_, kM, col, &P(col + 1), 1)) return 1;
     for (int i = 1; i <= col; i++) P(i) = -P(i) / std::sqrt(SY(i, i));
     for (int i = 1; i <= col; i++) {
       double sum = 0.;
@@ -398,7 +414,7 @@ class Lbfgsb {
   // LEL^T factorisation of the indefinite middle matrix of the subspace problem
   int formk() {
     int m = kM, col = col_, nsub = nfree_;
-    if (wn_.empty()) { wn_.assign((size_t)4 * kM * kM, 0); snd_.assign((size_t)4 * kM * kM, 0); }
+    if (!wn_ready_) { std::memset(wn_, 0, sizeof(double) * 8 * kM * kM); wn_ready_ = true; }
     int upcl;
     if (updatd_) {
       if (iupdat_ > m) {
@@ -503,10 +519,10 @@ class Lbfgsb {
       for (int jy = iy; jy <= col; jy++) WN(jy, is) = WN1(is1, jy);
       WN(iy, iy) += SY(iy, iy);
     }
-    if (dpofa(wn_.data(), m2, col)) return -1;
+    if (dpofa(wn_, m2, col)) return -1;
     int col2 = 2 * col;
     for (int js = col + 1; js <= col2; js++)
-      if (dtrsl(wn_.data(), m2, col, &WN(1, js), 11)) return -1;  // reference ignores this info; dpofa succeeded
+      if (dtrsl(wn_, m2, col, &WN(1, js), 11)) return -1;  // reference ignores this info; dpofa succeeded
     for (int is = col + 1; is <= col2; is++)
       for (int js = is; js <= col2; js++) WN(is, js) += ddot(col, &WN(1, is), 1, &WN(1, js), 1);
     if (dpofa(&WN(col + 1, col + 1), m2, col)) return -2;
@@ -523,7 +539,7 @@ class Lbfgsb {
         for (int k = 1; k <= k1; k++) ddum += SY(i, k) * SY(j, k) / SY(k, k);
         WT(i, j) = ddum + theta_ * SS(i, j);
       }
-    if (dpofa(wt_.data(), kM, col)) return -3;
+    if (dpofa(wt_, kM, col)) return -3;
     return 0;
   }
 
@@ -571,9 +587,9 @@ class Lbfgsb {
       pointr = pointr % m + 1;
     }
     int m2 = 2 * m, col2 = 2 * col;
-    if (dtrsl(wn_.data(), m2, col2, wv + 1, 11)) return 1;
+    if (dtrsl(wn_, m2, col2, wv + 1, 11)) return 1;
     for (int i = 1; i <= col; i++) wv[i] = -wv[i];
-    if (dtrsl(wn_.data(), m2, col2, wv + 1, 1)) return 1;
+    if (dtrsl(wn_, m2, col2, wv + 1, 1)) return 1;
     pointr = head_;
     for (int jy = 1; jy <= col; jy++) {
       int js = col + jy;

@@ -10,12 +10,15 @@
 #include <rccl/rccl.h>  // types and prototypes only: the library is looked up at run time (relate_hip_gather)
 
 #include <dlfcn.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -100,6 +103,37 @@ struct LaneBufs {
   }
 };
 
+// Storage of the optimiser runs of a fit: one slab per run (the run object, then the work matrices of its L-BFGS-B
+// state), handed out from 168 MB chunks and recycled run to run and block to block.  A block of 8 192 pairs with 8
+// restarts each has 65 536 runs alive at once = 5.6 GB; allocated object by object that was 1.4 million page faults
+// per block (0.5 s of every fit's host time).  The chunks ask for huge pages (the box grants them on madvise).
+constexpr size_t kFitRunBytes = 5376;
+constexpr size_t kFitSlabBytes = kFitRunBytes + sizeof(double) * Lbfgsb::kSlab;
+struct RunArena {
+  static constexpr size_t kPerChunk = 2048;
+  std::vector<void *> chunks;
+  std::vector<unsigned char *> free_;
+  unsigned char *take() {
+    if (free_.empty()) {
+      const size_t bytes = kPerChunk * kFitSlabBytes;
+      void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+      if (m == MAP_FAILED) return nullptr;
+      (void)madvise(m, bytes, MADV_HUGEPAGE);
+      chunks.push_back(m);
+      for (size_t i = kPerChunk; i-- > 0;) free_.push_back((unsigned char *)m + i * kFitSlabBytes);
+    }
+    unsigned char *s = free_.back();
+    free_.pop_back();
+    return s;
+  }
+  void give(unsigned char *s) { free_.push_back(s); }
+  void release() {
+    for (void *m : chunks) munmap(m, kPerChunk * kFitSlabBytes);
+    chunks.clear();
+    free_.clear();
+  }
+};
+
 }  // namespace
 
 struct relate_hip_ctx {
@@ -159,6 +193,8 @@ struct relate_hip_ctx {
   DBuf<unsigned char> dGatherS, dGatherR;
   unsigned char *scratch_dev = nullptr;  // device address of `scratch` on this handle's GPU (relate_hip_like_noalloc)
   long single_sweep_lanes = 45056;              // launches below this many lanes are cut along the SNP axis (pick_chunks)
+  RunArena run_arena;
+  int fit_eager = -1;  // what the previous fit of this data set saw: 1 = first waves of restarts rarely settle a pair (FitPop::eager)
 };
 
 namespace {
@@ -193,10 +229,64 @@ int host_threads() {
   }();
   return n;
 }
+// The workers are started once and kept (a round of a fit makes several passes of a few hundred microseconds each; a
+// thread start costs a good part of that).  One pass at a time: a second caller (another handle's host thread) or a
+// forked child, which has no workers, starts threads of its own as before.  Never destroyed: the workers sleep on a
+// condition variable until the process ends.
+class HostPool {
+ public:
+  explicit HostPool(int nt) : pid_(getpid()) {
+    for (int t = 1; t < nt; t++) th_.emplace_back([this, t] { worker(t); });
+  }
+  bool try_run(size_t n, const std::function<void(size_t, size_t)> &fn) {
+    if (getpid() != pid_) return false;
+    std::unique_lock<std::mutex> use(use_, std::try_to_lock);
+    if (!use.owns_lock()) return false;
+    const int nt = (int)th_.size() + 1;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      job_ = &fn; n_ = n; per_ = (n + nt - 1) / nt; pending_ = nt - 1; gen_++;
+    }
+    cv_work_.notify_all();
+    fn((size_t)0, std::min(n, per_));
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [&] { return pending_ == 0; });
+    return true;
+  }
+
+ private:
+  void worker(int t) {
+    long seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_work_.wait(lk, [&] { return gen_ != seen; });
+      seen = gen_;
+      const std::function<void(size_t, size_t)> *job = job_;
+      const size_t lo = (size_t)t * per_, hi = std::min(n_, lo + per_);
+      lk.unlock();
+      if (lo < hi) (*job)(lo, hi);
+      lk.lock();
+      if (--pending_ == 0) cv_done_.notify_one();
+    }
+  }
+  pid_t pid_;
+  std::vector<std::thread> th_;
+  std::mutex mu_, use_;
+  std::condition_variable cv_work_, cv_done_;
+  const std::function<void(size_t, size_t)> *job_ = nullptr;
+  size_t n_ = 0, per_ = 0;
+  long gen_ = 0;
+  int pending_ = 0;
+};
 template <class F>
-void parallel_for(size_t n, F &&fn) {  // fn(begin, end)
+void parallel_for(size_t n, F &&fn, size_t serial_below = 4096) {  // fn(begin, end)
   int nt = host_threads();
-  if (n < 4096 || nt == 1) { fn((size_t)0, n); return; }
+  if (n < serial_below || nt == 1) { fn((size_t)0, n); return; }
+  static HostPool *pool = new HostPool(nt);
+  {
+    const std::function<void(size_t, size_t)> job = [&fn](size_t lo, size_t hi) { fn(lo, hi); };
+    if (pool->try_run(n, job)) return;
+  }
   std::vector<std::thread> th;
   size_t per = (n + nt - 1) / nt;
   for (int t = 0; t < nt; t++) {
@@ -608,15 +698,27 @@ constexpr long kCompactBelowPoints = 45056;  // launches below this size are cut
 struct FitPop {
   struct Run {
     FindMax fm;
-    int pair, idx;          // pair = index inside the population
     int slot[7];            // for each requested point: lane index, or -1 if the wrapper short-circuits
-    size_t lane0 = 0;       // first lane of this run in the launch
-    bool waited = false;    // its request was held back in the previous round
-    bool taken = true;      // its request is part of this round's launch
     double akk[7][3];       // the request mapped to (a, k2, k1)
     bool ok[7];
-    int nlanes = 0;
     bool bad = false;
+    double *matrices() { return reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(this) + kFitRunBytes); }
+  };
+  RunArena *arena = nullptr;
+  void drop(Run *r) {  // the run's slab goes back to the arena
+    r->~Run();
+    arena->give(reinterpret_cast<unsigned char *>(r));
+  }
+  // What the scheduling passes of a round read of a run, side by side (the runs themselves are heap objects of tens of
+  // KB each: with 65 536 of them a serial pass over their fields is a cache miss per run).
+  struct Act {
+    Run *r;
+    int pair, idx;          // pair = index inside the population
+    int nlanes;             // points of its request that need the GPU
+    size_t lane0;           // first lane of this run in the launch
+    bool waited;            // its request was held back in the previous round
+    bool taken;             // its request is part of this round's launch
+    bool done;              // fm.done, as of the last consume()
   };
   int p0 = 0, P = 0;  // pairs [p0, p0 + P) of the staged block
   const relate_opts *o = nullptr;
@@ -629,17 +731,30 @@ struct FitPop {
   std::vector<GlibcRand> rng;
   std::vector<std::vector<double>> results;
   std::vector<std::vector<char>> have;
-  std::vector<Run *> active;
+  std::vector<Act> active;
   bool first_round = true, inflight = false, finished = false;
   LaneBufs *B = nullptr;
   std::vector<int> col;                          // column of every pair in the record block
   int ncols = 0;                                 // columns [p0, p0 + ncols) hold this population's live pairs
   std::function<int(FitPop &, const std::vector<int> &)> restage;  // stages the given pairs into columns p0, p0 + 1, ...
   int ul = 2;                                    // slots per pair of the uLike / poLike points in the first launch
+  // Restarts ahead of need.  The multi-start rule starts the minimum of runs that could settle a pair and waits for
+  // them; where they rarely do (the 2-parameter calcA mode: no two of 8 runs agree) that serialises a pair
+  // into two waves and keeps the launches at a quarter of the runs the block has to make anyway.  Once the first
+  // waves seen so far (here, or in the previous fit of the handle) have left at least 3 of 4 pairs unsettled, every
+  // pair starts all its remaining runs at once.  Outcomes do not change: starts are drawn and results consumed in
+  // index order, runs beyond the stopping point are dropped unseen.  RELATE_FIT_EAGER = 0 | 1 overrides.
+  bool eager = false;
+  int eager_forced = -1;
+  long seen_first = 0, seen_unsettled = 0;       // pairs whose first wave has been consumed / that needed more runs
+  static constexpr size_t kMaxActiveRuns = 98304;  // ~80 KB of L-BFGS-B state each
   std::vector<std::pair<size_t, size_t>> pads;   // slot gaps [first, second) of the launch being laid out
+  std::vector<int> pair_pts;                     // points of each pair taken into the launch being laid out
+  bool long_rows = true;                         // rows long enough that the kernels, not the rounds, set the time
 
   ~FitPop() {
-    for (Run *r : active) delete r;
+    for (Act &a : active)
+      if (a.r) drop(a.r);
   }
   void init(int p0_, int P_, const relate_opts *o_, const FitSpec &S_, const double *starts_, long pair_base_,
             LaneBufs *B_, const int *nsnp) {
@@ -669,57 +784,83 @@ struct FitPop {
   // returns the number of lanes laid out in B, or -1 on a pinned-memory error; sets `finished` when no run is left.
   // Zero lanes with runs left is possible: every requested point short-circuits in its wrapper (infeasible k).
   long prepare() {
-    auto by_pair = [](const Run *x, const Run *y) { return x->pair != y->pair ? x->pair < y->pair : x->idx < y->idx; };
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tq = tnow();
+    auto lap = [&](int k) { double t = tnow(); tprep[k] += t - tq; tq = t; };
+    auto by_pair = [](const Act &x, const Act &y) { return x.pair != y.pair ? x.pair < y.pair : x.idx < y.idx; };
+    std::vector<std::array<double, 3>> x0s;
     for (;;) {
       // `active` stays sorted by (pair, restart): lanes of one pair side by side read the same records, so a wave
       // touches ~13 distinct records per step instead of 64 (measured 250 -> 330 G lane-steps/s on the chunked
       // path).  New runs arrive in that order at the tail and are merged in; retired runs are removed in place.
       const size_t n_before = active.size();
+      x0s.clear();
       for (int p = 0; p < P; p++) {
-        int w = ms[p].want_to_launch();
+        int w = ms[p].want_to_launch(eager && ms[p].launched > 0);
+        if (w > 0 && ms[p].launched > ms[p].consumed && active.size() + w > kMaxActiveRuns) w = 0;  // ahead of need: bounded
         for (int q = 0; q < w; q++) {
-          Run *r = new Run();
-          r->pair = p;
-          r->idx = ms[p].launched++;
-          double st[4], x0[3];
-          if (starts) std::memcpy(st, starts + ((size_t)(pair_base + p0 + p) * R + r->idx) * 4, sizeof(st));
-          else draw_start(rng[p], S, o->fixK, st);
-          start_to_x(S, st, x0);
-          r->fm.begin(n, x0, lo, hi);
-          active.push_back(r);
+          Act a{nullptr, p, ms[p].launched++, 0, 0, false, true, false};
+          double st[4];
+          std::array<double, 3> x0;
+          if (starts) std::memcpy(st, starts + ((size_t)(pair_base + p0 + p) * R + a.idx) * 4, sizeof(st));
+          else draw_start(rng[p], S, o->fixK, st);  // the pair's rand() stream: in index order
+          start_to_x(S, st, x0.data());
+          a.r = reinterpret_cast<Run *>(arena->take());
+          if (!a.r) return -1;
+          x0s.push_back(x0);
+          active.push_back(a);
         }
       }
+      parallel_for(x0s.size(), [&](size_t lo_, size_t hi_) {  // the optimiser states (their matrices are cleared here)
+        for (size_t i = lo_; i < hi_; i++) {
+          Run *r = new (active[n_before + i].r) Run();
+          r->fm.begin(n, x0s[i].data(), lo, hi, r->matrices());
+          active[n_before + i].r = r;
+          active[n_before + i].done = r->fm.done;
+        }
+      }, 256);
       if (n_before > 0 && active.size() > n_before)
         std::inplace_merge(active.begin(), active.begin() + n_before, active.end(), by_pair);
+      lap(0);
       // retire finished runs, feed the multi-start rule in index order
       bool relaunch = false;
       for (bool progressed = true; progressed && !relaunch;) {
         progressed = false;
         size_t keep_n = 0;
         for (size_t i = 0; i < active.size(); i++) {
-          Run *r = active[i];
-          if (r->fm.done) {
-            x_to_result(S, r->fm.opt.x, r->fm.like, &results[r->pair][(size_t)r->idx * 4]);
-            have[r->pair][r->idx] = 1;
-            delete r;
+          const Act &a = active[i];
+          if (a.done) {
+            x_to_result(S, a.r->fm.opt.x, a.r->fm.like, &results[a.pair][(size_t)a.idx * 4]);
+            have[a.pair][a.idx] = 1;
+            drop(a.r);
             progressed = true;
           } else
-            active[keep_n++] = r;
+            active[keep_n++] = a;
         }
         active.resize(keep_n);
         for (int p = 0; p < P; p++)
-          while (!ms[p].finished && ms[p].consumed < ms[p].launched && have[p][ms[p].consumed])
+          while (!ms[p].finished && ms[p].consumed < ms[p].launched && have[p][ms[p].consumed]) {
             ms[p].consume(&results[p][(size_t)ms[p].consumed * 4]);
+            if (ms[p].consumed == ms[p].first_wave()) {
+              seen_first++;
+              if (!ms[p].finished) seen_unsettled++;
+            }
+          }
+        if (!eager && eager_forced != 0 && seen_first >= std::max(32L, (long)P / 64) && seen_unsettled * 4 >= seen_first * 3)
+          eager = true;
         // runs started ahead of need for a pair whose rule has stopped meanwhile are dropped unseen
         keep_n = 0;
         for (size_t i = 0; i < active.size(); i++) {
-          if (ms[active[i]->pair].finished) delete active[i];
+          if (ms[active[i].pair].finished) drop(active[i].r);
           else active[keep_n++] = active[i];
         }
         active.resize(keep_n);
-        for (int p = 0; p < P && !relaunch; p++)
-          if (ms[p].want_to_launch() > 0) relaunch = true;
+        for (int p = 0; p < P && !relaunch; p++) {
+          int w = ms[p].want_to_launch(eager && ms[p].launched > 0);
+          if (w > 0 && !(ms[p].launched > ms[p].consumed && active.size() + w > kMaxActiveRuns)) relaunch = true;
+        }
       }
+      lap(1);
       if (relaunch) continue;
       break;
     }
@@ -735,16 +876,18 @@ struct FitPop {
     const long kTurn = 2 * 256L * 4 * 64;
     parallel_for(active.size(), [&](size_t lo_, size_t hi_) {
       for (size_t i = lo_; i < hi_; i++) {  // lanes a run needs: the points its wrapper does not short-circuit
-        Run *r = active[i];
-        r->nlanes = 0;
+        Run *r = active[i].r;
+        int nl = 0;
         for (int q = 0; q < r->fm.npts; q++) {
           r->ok[q] = map_point(S, r->fm.pts[q], r->akk[q]);
-          r->nlanes += r->ok[q] ? 1 : 0;
+          nl += r->ok[q] ? 1 : 0;
         }
+        active[i].nlanes = nl;
       }
     });
     long want = 0;
-    for (Run *r : active) want += r->nlanes;
+    for (const Act &a : active) want += a.nlanes;
+    lap(2);
     // Few pairs left, scattered over the block's columns: every lane then pulls whole 128-byte lines for the 16 bytes
     // of its pair (a launch of 1 300 points over 260 scattered pairs ran HBM-bound at 136 G point-steps/s against
     // ~460 G dense).  Once the live pairs are a quarter of the columns they occupy, their records are staged again
@@ -759,42 +902,57 @@ struct FitPop {
         ncols = (int)live.size();
       }
     }
-    long budget = (!first_round && want > kTurn) ? (want / kTurn) * kTurn : want;
-    long used = 0;
-    for (Run *r : active) {
-      r->taken = r->waited;
-      if (r->taken) used += r->nlanes;
-    }
-    for (Run *r : active) {
-      if (r->taken) continue;
-      if (used + r->nlanes <= budget) {
-        r->taken = true;
-        used += r->nlanes;
-      }
+    lap(3);
+    // The brackets of launch_like at long rows: <= 65 536 slots 43 ms, <= 98 304 60 ms, <= 131 072 68 ms,
+    // <= 262 144 122 ms at M = 5e5.  A round that falls just above a bracket launches the bracket and holds the rest.
+    long budget = want;
+    if (!first_round && long_rows) {
+      if (want > 2 * kTurn) budget = 2 * kTurn;
+      else if (want > kTurn && want < kTurn * 9 / 5) budget = kTurn;
+      else if (want > kTurn / 2 && want < kTurn * 11 / 16) budget = kTurn / 2;
     }
     // Slots.  A lane of the likelihood kernels may carry nv points of one pair (pick_nv): every pair's points start at
-    // a multiple of nv and are padded to one with copies of its last point (values never read).
+    // a multiple of nv and are padded to one with copies of its last point (values never read); the budget counts
+    // slots, padding included (a launch one slot above a bracket pays the next bracket).
     // uLike / poLike (:3478-3481) ride along with the first launch: slots p * ul, p * ul + 1
-    const int nv = pick_nv(used + (first_round ? 2L * P : 0), 2);
+    const int nv = pick_nv(std::min(want, budget) + (first_round ? 2L * P : 0), 2);
     auto up = [nv](size_t x) { return (x + nv - 1) / nv * nv; };
+    long used = 0;
+    pair_pts.assign(P, 0);
+    for (Act &a : active) {
+      a.taken = a.waited;
+      if (a.taken) pair_pts[a.pair] += a.nlanes;
+    }
+    for (int p = 0; p < P; p++) used += (long)up(pair_pts[p]);
+    for (Act &a : active) {
+      if (a.taken) continue;
+      const long delta = (long)up(pair_pts[a.pair] + a.nlanes) - (long)up(pair_pts[a.pair]);
+      if (used + delta <= budget) {
+        a.taken = true;
+        used += delta;
+        pair_pts[a.pair] += a.nlanes;
+      }
+    }
     B->nv = nv;
     ul = (int)up(2);
     size_t nl_total = first_round ? (size_t)ul * P : 0;
     pads.clear();
     int prev_pair = -1;
-    for (Run *r : active) {
-      r->waited = !r->taken;
-      if (r->taken && r->nlanes > 0 && r->pair != prev_pair) {
+    for (Act &a : active) {
+      a.waited = !a.taken;
+      if (a.taken && a.nlanes > 0 && a.pair != prev_pair) {
         if (nl_total % nv) pads.push_back({nl_total, up(nl_total)});
         nl_total = up(nl_total);
-        prev_pair = r->pair;
+        prev_pair = a.pair;
       }
-      r->lane0 = nl_total;
-      if (r->taken) nl_total += r->nlanes;
+      a.lane0 = nl_total;
+      if (a.taken) nl_total += a.nlanes;
     }
     if (nl_total % nv) pads.push_back({nl_total, up(nl_total)});
     nl_total = up(nl_total);
+    lap(4);
     if (B->ensure(nl_total) != hipSuccess) return -1;
+    lap(5);
     B->nl = (int)nl_total;
     if (first_round)
       for (int p = 0; p < P; p++)
@@ -805,14 +963,15 @@ struct FitPop {
         }
     parallel_for(active.size(), [&](size_t lo_, size_t hi_) {
       for (size_t i = lo_; i < hi_; i++) {
-        Run *r = active[i];
-        if (!r->taken) continue;
-        size_t at = r->lane0;
+        if (!active[i].taken) continue;
+        Run *r = active[i].r;
+        size_t at = active[i].lane0;
+        const int column = col[active[i].pair];
         for (int q = 0; q < r->fm.npts; q++) {
           r->slot[q] = -1;
           if (r->ok[q]) {
             r->slot[q] = (int)at;
-            B->lane[at] = col[r->pair];
+            B->lane[at] = column;
             B->par[3 * at] = r->akk[q][0]; B->par[3 * at + 1] = r->akk[q][1]; B->par[3 * at + 2] = r->akk[q][2];
             at++;
           }
@@ -824,8 +983,10 @@ struct FitPop {
         B->lane[at] = B->lane[g.first - 1];
         for (int c = 0; c < 3; c++) B->par[3 * at + c] = B->par[3 * (g.first - 1) + c];
       }
+    lap(6);
     return (long)nl_total;
   }
+  double tprep[7] = {0, 0, 0, 0, 0, 0, 0};  // seconds by phase of prepare(): start runs, retire, map points, restage, select, pinned buffers, lay out
 
   void consume(relate_fit *out) {  // out: records of the staged block
     const double *val = B->val;
@@ -836,10 +997,11 @@ struct FitPop {
       }
       first_round = false;
     }
+    std::atomic<bool> bad_seen{false};
     parallel_for(active.size(), [&](size_t lo_, size_t hi_) {
       for (size_t i = lo_; i < hi_; i++) {
-        Run *r = active[i];
-        if (!r->taken) continue;
+        if (!active[i].taken) continue;
+        Run *r = active[i].r;
         double v[7];
         bool bad = false;
         for (int q = 0; q < r->fm.npts; q++) {
@@ -850,13 +1012,17 @@ struct FitPop {
           r->bad = true;
           r->fm.done = true;
           r->fm.like = NAN;
+          active[i].done = true;
+          bad_seen.store(true, std::memory_order_relaxed);
           continue;
         }
         r->fm.supply(v);
+        active[i].done = r->fm.done;
       }
     });
-    for (Run *r : active)
-      if (r->bad) out[p0 + r->pair].status = RELATE_E_NUMERIC;
+    if (bad_seen.load())
+      for (const Act &a : active)
+        if (a.r->bad) out[p0 + a.pair].status = RELATE_E_NUMERIC;
   }
 
   void finish(relate_fit *out, double *conv_out) {
@@ -875,6 +1041,8 @@ struct FitPop {
     }
   }
 };
+
+static_assert(sizeof(FitPop::Run) <= kFitRunBytes && kFitSlabBytes % 64 == 0, "a run and its matrices share one slab");
 
 // fills out[0..P) (and conv_out rows pair_base..) for the P pairs of the staged block
 int fit_block(relate_hip_t h, int P, long pair_base, const double *starts, relate_fit *out, double *conv_out) {
@@ -932,6 +1100,10 @@ int fit_block(relate_hip_t h, int P, long pair_base, const double *starts, relat
   for (int k = 0; k < npop; k++) {
     int b = (int)((long)P * k / npop), e = (int)((long)P * (k + 1) / npop);
     pop[k].init(b, e - b, &o, S, starts, pair_base, &h->lanebufs[k], h->h_nsnp.data());
+    if (const char *ee = getenv("RELATE_FIT_EAGER")) pop[k].eager_forced = atoi(ee) ? 1 : 0;
+    pop[k].long_rows = h->M >= 16384;
+    pop[k].arena = &h->run_arena;
+    pop[k].eager = pop[k].eager_forced >= 0 ? pop[k].eager_forced == 1 : h->fit_eager == 1;
     if (compact && (int)blk.size() == 2 * P)
       pop[k].restage = [h, &blk](FitPop &F, const std::vector<int> &live) -> int {
         std::vector<int32_t> sub(2 * live.size());
@@ -946,12 +1118,16 @@ int fit_block(relate_hip_t h, int P, long pair_base, const double *starts, relat
         return rc;
       };
   }
+  double t_prep = 0, t_cons = 0, t_wait = 0;  // host seconds by phase (RELATE_FIT_TRACE)
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   auto start = [&](FitPop &F) -> int {
     F.inflight = false;
     for (;;) {
+      const double t0 = now();
       long nl = F.prepare();
+      t_prep += now() - t0;
       if (nl == -2) return RELATE_E_HIP;  // staging the live pairs again failed: the message is set
-      if (nl < 0) return fail(h, RELATE_E_NOMEM, "pinned host memory for the likelihood lanes");
+      if (nl < 0) return fail(h, RELATE_E_NOMEM, "host memory for the optimiser runs or the likelihood lanes");
       if (F.finished) return 0;
       if (nl > 0) {
         F.inflight = true;
@@ -968,9 +1144,13 @@ int fit_block(relate_hip_t h, int P, long pair_base, const double *starts, relat
       FitPop &F = pop[k];
       if (!F.inflight) continue;
       any = true;
+      double t0 = now();
       rc = like_wait(h, *F.B);
+      t_wait += now() - t0;
       if (rc) break;
+      t0 = now();
       F.consume(out);
+      t_cons += now() - t0;
       rc = start(F);
     }
   }
@@ -979,6 +1159,16 @@ int fit_block(relate_hip_t h, int P, long pair_base, const double *starts, relat
     return rc;
   }
   for (int k = 0; k < npop; k++) pop[k].finish(out, conv_out);
+  {
+    long first = 0, unsettled = 0;
+    for (int k = 0; k < npop; k++) { first += pop[k].seen_first; unsettled += pop[k].seen_unsettled; }
+    if (first >= 32) h->fit_eager = unsettled * 4 >= first * 3 ? 1 : 0;
+  }
+  if (getenv("RELATE_FIT_TRACE"))
+    std::fprintf(stderr, "fit block: %d pairs, host prepare %.3f s (start runs %.3f, retire %.3f, map points %.3f, restage %.3f, "
+                 "select %.3f, pinned buffers %.3f, lay out %.3f), consume %.3f s, waiting on the GPU %.3f s\n", P, t_prep,
+                 pop[0].tprep[0], pop[0].tprep[1], pop[0].tprep[2], pop[0].tprep[3], pop[0].tprep[4], pop[0].tprep[5],
+                 pop[0].tprep[6], t_cons, t_wait);
   return 0;
 }
 
@@ -1200,6 +1390,7 @@ int relate_hip_destroy(relate_hip_t h) {
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   gather_release(h);
   if (h->stream) (void)hipStreamDestroy(h->stream);
+  h->run_arena.release();
   delete h;
   return RELATE_OK;
 }
@@ -1278,6 +1469,7 @@ int relate_hip_load(relate_hip_t h, const uint8_t *geno, int N, int M_raw, const
   else h->h_chr_raw.assign(M_raw, -1);
   h->loaded = true;
   h->ready = false;
+  h->fit_eager = -1;
   h->staged.clear();
   h->stagedV.clear();
   return RELATE_OK;
@@ -1308,6 +1500,7 @@ int relate_hip_load_bed(relate_hip_t h, const uint8_t *bed, int N, int n_snp_bed
   else h->h_chr_raw.assign(M_raw, -1);
   h->loaded = true;
   h->ready = false;
+  h->fit_eager = -1;
   h->staged.clear();
   h->stagedV.clear();
   return RELATE_OK;
