@@ -30,17 +30,19 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s achievable)
 
-# Algorithmic bytes per (pair, SNP) of one launch by this design: emission record 24 B (three
-# planes: t, S1/S0, S2/S0); packed genotypes 2 x 2 bit; tile checkpoint 84 B per 16 SNPs; posterior 3 x 8 B.  The decode is
-# two sweeps over the records: chunk products + tile checkpoints, then the backward sweep that writes the posteriors.
+# Algorithmic bytes per (pair, SNP) of one launch by this design: emission record 16 B (two
+# planes: S1/S0, S2/S0; the distance of a step is the shared per-SNP one, M x 8 B for the whole block); packed genotypes
+# 2 x 2 bit; tile checkpoint 84 B per 16 SNPs; posterior 3 x 8 B.  The decode is two sweeps over the records: chunk
+# products + tile checkpoints, then the backward sweep that writes the posteriors.
 CKPT = 84.0 / 16
+REC = 16.0
 
 
 def algorithmic_bytes(like_chunks, decode_chunks):
-    return {"stage": 24.0 + 0.5 + 0.25,
-            "like": 24.0,
-            "decode_fwd": 24.0 + CKPT,
-            "decode_bwd": 24.0 + CKPT + 24.0}
+    return {"stage": REC + 0.5 + 0.25,
+            "like": REC,
+            "decode_fwd": REC + CKPT,
+            "decode_bwd": REC + CKPT + 24.0}
 
 
 # SURVEY.md section 8(d)'s figures, which price the path without materialised emissions: two 2-bit genotypes per forward
@@ -253,7 +255,7 @@ def linkage_leg(local, inds, snps, allp, npairs):
     t_dec = time.perf_counter() - t0
     tm = H.timings()
     out = {"pairs": int(npairs), "snps_after_maf_and_pruning": int(M), "load_precalc_prune_s": t_pre,
-           "stage_ms": stage_ms, "stage_gbs": (24.75 * npairs * M) / (stage_ms * 1e-3) / 1e9 if stage_ms else None,
+           "stage_ms": stage_ms, "stage_gbs": ((REC + 0.75) * npairs * M) / (stage_ms * 1e-3) / 1e9 if stage_ms else None,
            "fit_seconds": t_fit, "fit_pairs_per_s": npairs / t_fit, "fit_like_kernel_seconds": tm["like_ms"] / 1e3,
            "decode_rows1_pairs": int(min(npairs, 1024)), "decode_rows1_seconds_with_host_copy": t_dec,
            "pairs_not_ok": int(sum(r["status"] != 0 for r in res)),

@@ -2,26 +2,40 @@
 // Replaces error/errorNoLD/emission2_new/errorLD/LDemission_new/LD2_new and the per-pair table
 // re-indexing remove_cross/getHighestId (src/relateHMM.cpp:2776-2975, 850-971, 481-497).  gfx950 only.
 //
-// Emission records live SNP-major in HBM, 24 B per pair and SNP: t, S_ibd1 / S_ibd0, S_ibd2 / S_ibd0.  Two consecutive
-// SNPs share a row, and a row holds the pairs of the staged block in groups of 64 (one wave); a group keeps its three
-// values as three planes of 64 x {SNP 2h, SNP 2h+1} (16 B per pair and plane, 3 072 B per group), so a wave fetches two
-// records of each of its pairs with three 16-byte loads -- 1.5 vector-memory instructions per record, every one
-// a contiguous KiB (the address unit does ~20 cycles of work per wave instruction whatever its width, and the sweeps
+// Emission records live SNP-major in HBM, 16 B per pair and SNP: S_ibd1 / S_ibd0, S_ibd2 / S_ibd0.  Two consecutive
+// SNPs share a row, and a row holds the pairs of the staged block in groups of 64 (one wave); a group keeps its two
+// values as two planes of 64 x {SNP 2h, SNP 2h+1} (16 B per pair and plane, 2 048 B per group), so a wave fetches two
+// records of each of its pairs with two 16-byte loads -- one vector-memory instruction per record, every one a
+// contiguous KiB (the address unit does ~20 cycles of work per wave instruction whatever its width, and the sweeps
 // are bound by it before they are bound by bytes):
-//     rec[(s / 2) * 6 * RP + (p / 64) * 384 + c * 128 + (p % 64) * 2 + s % 2],   c = 0: t, 1: S1/S0, 2: S2/S0
+//     rec[(s / 2) * 4 * RP + (p / 64) * 256 + c * 128 + (p % 64) * 2 + s % 2],   c = 0: S1/S0, 1: S2/S0
 // (RP = pairs rounded up to a multiple of 64, chosen by the host so that consecutive rows do not lie a power of
 // two apart).  Emissions matter to the recursions only up to a per-SNP factor: the factor S_ibd0 is
 // taken out here, multiplied up per pair (mantissa and power-of-two exponent, scale_reduce_kernel) and added to the
-// log-likelihood once; it cancels in posteriors.  A SNP dropped for the pair (a missing genotype) is {-0.0, 1, 1}
-// with factor 1: an identity step for the recursions, flagged by the sign bit of t; the pair's first kept SNP has
-// t = +0.0 (the reference's t[0] = 0).  The "full" format (Viterbi, inspection) has four planes t, S_ibd0, S_ibd1, S_ibd2.
+// log-likelihood once; it cancels in posteriors.
+//
+// Distances are NOT in the record.  The reference gives a pair the distance between its consecutive KEPT SNPs
+// (diff, src/relateHMM.cpp:391-404); here every SNP -- kept or dropped for the pair -- steps by the shared distance
+// tsh[s] = pos[s] - pos[s-1] (negative: 1e7, as diff has it; tsh[0] = 0), a dropped SNP with emission (1, 1, 1): the
+// transition matrices form a semigroup, T(t1) T(t2) = T(t1 + t2) (both of the reference's models are e^{Qt}), so the
+// steps over a run of dropped SNPs compose to the reference's single step, and the start vector k is stationary
+// (k T = k), so dropped SNPs in front of the first kept one change nothing.  A third of the bytes of every sweep,
+// and the distance is wave-uniform (scalar loads, scalar tier test).  Record values: kept (r1 >= 0, r2 >= 0);
+// dropped (-1, +1) -- the sign bit of r1 is the "dropped" flag, the recursions multiply by |r1|.
+// One case does not compose: a run of dropped SNPs across a chromosome break whose two kept ends have a NON-negative
+// position difference d (the reference then steps by T(d), not by the break's 1e7).  boundary_fixup_kernel finds
+// those runs (a handful of genotype reads per pair and break) and marks their records with the sign bit of r2 =
+// "this lane's distance is not the shared one": dropped (-1, -tau) steps by tau, kept (r1, -r2) by 0; the run's
+// SNPs get tau = 0 except the last dropped one, which gets d.  The sweeps test the sign bits of a group's r2 with
+// one ballot and take a per-lane-distance path for such a group.
+// The "full" format (Viterbi, inspection) has four planes t, S_ibd0, S_ibd1, S_ibd2 with the pair's own distances.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace relate {
 
-static constexpr int kRecPlanes = 3, kRecPlanesFull = 4;
+static constexpr int kRecPlanes = 2, kRecPlanesFull = 4;
 // offset in doubles of SNP s, pair column col in a block of npl planes and padded pair count RP; plane c is c * 128 further
 __host__ __device__ inline size_t rec_off(int s, int col, int npl, int RP) {
   return (size_t)(s >> 1) * (2 * npl) * RP + (size_t)(col >> 6) * (npl * 128) + (col & 63) * 2 + (s & 1);
@@ -48,17 +62,16 @@ struct ScaleAcc {
 };
 
 // One staged record of a lane.  state: 0 dropped, 1/2 kept with entry {s0, r1, r2}, 3 all-zero emission.  Returns the
-// values of the planes (FULL: t, S0, S1, S2; else t, S1/S0, S2/S0) and folds the factor into acc.
+// values of the planes (FULL: t, S0, S1, S2; else S1/S0, S2/S0) and folds the factor into acc.
 template <bool FULL>
 __device__ inline void make_record(int state, double t, double s0, double r1, double r2, ScaleAcc &acc, int &nkept,
-                                   double (&out)[FULL ? 4 : 3]) {
+                                   double (&out)[FULL ? 4 : 2]) {
   if (state == 0) { t = -0.0; s0 = 1; r1 = 1; r2 = 1; }
   else if (state == 3) { s0 = 0; r1 = 0; r2 = 0; }
   nkept += state != 0;
   acc.m *= s0;
-  out[0] = t;
-  if (FULL) { out[1] = s0; out[2] = r1 * s0; out[3] = r2 * s0; }
-  else { out[1] = r1; out[2] = r2; }
+  if constexpr (FULL) { out[0] = t; out[1] = s0; out[2] = r1 * s0; out[3] = r2 * s0; }
+  else { out[0] = state == 0 ? -1.0 : r1; out[1] = r2; }
 }
 template <bool FULL>
 __device__ inline void put_record(double *__restrict__ rec, int RP, int s, int p, int state, double t, double s0,
@@ -271,7 +284,7 @@ __global__ void stage_pairs_kernel(const uint64_t *__restrict__ G, int M, int W,
       run = 0;  // identity step; sign bit of t = dropped
     } else {
       state = 2;
-      if (last >= 0) {  // else first kept SNP: t[0] = 0 in diff (:391-404); unconditional emission (LD2_new :2955-2957)
+      if (FULL && last >= 0) {  // else first kept SNP: t[0] = 0 in diff (:391-404); unconditional emission (LD2_new :2955-2957)
         double d = pos[s] - pos[last];
         t = d < 0 ? 10000000.0 : d;
       }
@@ -513,8 +526,10 @@ stage_pairs_win_kernel(const uint64_t *__restrict__ Gt, int M, int Wt, const int
           state[u] = 1;
         } else {
           state[u] = 2;
-          tpos[u] = pos[s];
-          lpos[u] = pos[last];
+          if constexpr (FULL) {
+            tpos[u] = pos[s];
+            lpos[u] = pos[last];
+          }
           if (useLD) {
             // kept flags of SNPs s-32 .. s-1 (bit 2j <-> SNP s-32+j), then reversed: bit 2*dd <-> SNP s-1-dd
             uint64_t Wk = k ? ((K_lo >> (2 * k)) | (K_hi << (64 - 2 * k))) : K_lo;
@@ -586,6 +601,35 @@ stage_pairs_win_kernel(const uint64_t *__restrict__ Gt, int M, int Wt, const int
   sc_m[(size_t)c * RP + col0 + p] = acc.m;
   sc_e[(size_t)c * RP + col0 + p] = acc.e;
   sc_n[(size_t)c * RP + col0 + p] = nkept;
+}
+
+// Runs of dropped SNPs across a chromosome break whose kept ends lie a non-negative distance apart (header): one
+// thread per (pair, break).  bnd[b] = first SNP of a chromosome (pos[s] < pos[s-1]).  L = last kept SNP before the
+// break, F = first kept SNP from the break on; if SNPs were dropped in between and pos[F] - pos[L] >= 0 the records
+// of (L, F] are marked.  Several breaks inside one run find the same L and F and write the same values.
+__global__ void boundary_fixup_kernel(const uint64_t *__restrict__ G, int M, int W, const int32_t *__restrict__ pairs,
+                                      int P, const int *__restrict__ bnd, int nb, const double *__restrict__ pos,
+                                      double *__restrict__ rec, int RP, int col0, int *__restrict__ own) {
+  long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (long)P * nb) return;
+  const int p = (int)(tid % P), b = bnd[tid / P];
+  const int i1 = pairs[2 * p], i2 = pairs[2 * p + 1];
+  int L = -1, F = -1;
+  for (int s = b - 1; s >= 0; s--)
+    if (geno_at(G, W, s, i1) && geno_at(G, W, s, i2)) { L = s; break; }
+  for (int s = b; s < M; s++)
+    if (geno_at(G, W, s, i1) && geno_at(G, W, s, i2)) { F = s; break; }
+  if (L < 0 || F < 0 || F == L + 1) return;
+  const double d = pos[F] - pos[L];
+  if (d < 0) return;  // the reference steps by 1e7 and so does the shared distance of the break
+  for (int s = L + 1; s < F; s++) {
+    double *q = rec + rec_off(s, col0 + p, kRecPlanes, RP);
+    q[0] = -1.0;
+    q[128] = s == F - 1 ? -d : -0.0;
+  }
+  double *q = rec + rec_off(F, col0 + p, kRecPlanes, RP);
+  q[128] = -fabs(q[128]);
+  own[col0 + p] = 1;
 }
 
 }  // namespace relate

@@ -17,13 +17,16 @@
 // polynomials in -a t with per-lane coefficients (LaneC); a forward step is then 13 + 14 FP64 instructions per
 // vector.  like() is reproduced to <= 1e-13 relative (tests/test_gpu_parity.py).
 //
-// Records (kernels_emis.hpp).  t, S_ibd1/S_ibd0, S_ibd2/S_ibd0 (24 B per pair and SNP) as three planes per group of 64
-// pairs, two consecutive SNPs per 16-byte element: three wave loads bring two records of every lane.  The recursions need emissions only up to a per-SNP factor: S_ibd0 is taken out
-// at staging time, its product per pair (mantissa sc_m, exponent sc_e) enters the log-likelihood once at the end and
-// cancels in posteriors -- a quarter of the bytes of every sweep and one multiply per vector-step less.  A SNP dropped
-// for the pair is {-0.0, 1, 1}: T(0) = I exactly, so the step is the identity and no lane ever branches on it; the
-// sign bit of t is the "dropped" flag for the kernels that must know (posterior = -1, Viterbi).  The pair's first kept
-// SNP has t = +0.0 (the reference's t[0] = 0): the start vector k passes through T(0) = I and picks up S.
+// Records (kernels_emis.hpp).  S_ibd1/S_ibd0, S_ibd2/S_ibd0 (16 B per pair and SNP) as two planes per group of 64
+// pairs, two consecutive SNPs per 16-byte element: two wave loads bring two records of every lane.  The recursions need
+// emissions only up to a per-SNP factor: S_ibd0 is taken out at staging time, its product per pair (mantissa sc_m,
+// exponent sc_e) enters the log-likelihood once at the end and cancels in posteriors.  The distance of a step is the
+// SHARED tsh[s] = pos[s] - pos[s-1] (scalar loads): a SNP dropped for the pair is (-1, 1), a step with emission
+// (1, 1, 1) -- T(t1) T(t2) = T(t1 + t2), so the steps over dropped SNPs compose to the reference's one step between
+// kept SNPs, no lane branches on missing data, and k T = k lets dropped SNPs precede the first kept one.  The sign bit
+// of r1 is the "dropped" flag for the kernels that must know (posterior = -1); the sign bit of r2 marks the rare record
+// that carries its own distance (a run of dropped SNPs across a chromosome break, kernels_emis.hpp): a group of records
+// with such a lane goes through the general-distance code with per-lane t (rec_lane).
 //
 // Parallelism.  One lane = one (pair, parameter point).  When a launch has too few lanes to fill 256 CUs the SNP
 // axis is cut into C chunks: the per-step matrices A_s = T(t_s) diag(S_s) compose associatively,
@@ -45,30 +48,34 @@ namespace relate {
 static constexpr int kGroup = 4;     // records per load group (two groups in flight)
 
 struct Rec {
-  double t, r1, r2;  // distance to the previous kept SNP, S_ibd1 / S_ibd0, S_ibd2 / S_ibd0
+  double t, r1, r2;  // distance of the step (shared, wave-uniform on the hot path), S_ibd1 / S_ibd0, S_ibd2 / S_ibd0
 };
 // One pair's column of the staged block: wave-uniform base (the SNP loops are uniform, so the row address is scalar)
 // plus the lane's byte offset.
 struct RecCol {
   const double *__restrict__ base;
-  size_t row;    // stride in doubles of a row of two SNPs (3 planes x padded pairs x 2)
+  const double *__restrict__ tsh;  // shared distances, M rounded up to even + 2 entries
+  size_t row;    // stride in doubles of a row of two SNPs (2 planes x padded pairs x 2)
   unsigned off;  // byte offset of the pair's column inside a row
   int hmax;      // last valid row (prefetches beyond the data are clamped to it)
-  __device__ RecCol(const double *rec, int RP, int col, int M)
-      : base(rec), row((size_t)2 * kRecPlanes * RP), off(8u * (unsigned)rec_off(0, col, kRecPlanes, RP)), hmax((M - 1) >> 1) {}
-  // records of SNPs 2h and 2h + 1
+  bool general;  // some lane of this wave sits on a pair with records that carry their own distance (own[col] != 0)
+  __device__ RecCol(const double *rec, const double *tshared, const int *own, int RP, int col, int M)
+      : base(rec), tsh(tshared), row((size_t)2 * kRecPlanes * RP), off(8u * (unsigned)rec_off(0, col, kRecPlanes, RP)),
+        hmax((M - 1) >> 1), general(__builtin_amdgcn_ballot_w64(own[col] != 0) != 0) {}
+  // records of SNPs 2h and 2h + 1 (h is wave-uniform: the distances are scalar loads)
   __device__ inline void at2(int h, Rec &a, Rec &b) const {
     const char *q = (const char *)(base + (size_t)h * row) + off;
-    const double2 t = *(const double2 *)q, r1 = *(const double2 *)(q + 1024), r2 = *(const double2 *)(q + 2048);
+    const double2 r1 = *(const double2 *)q, r2 = *(const double2 *)(q + 1024);
+    const double2 t = *(const double2 *)(tsh + 2 * (size_t)h);
     a.t = t.x; a.r1 = r1.x; a.r2 = r2.x;
     b.t = t.y; b.r1 = r1.y; b.r2 = r2.y;
   }
   __device__ inline Rec at(int s) const {  // one record (tails)
     const char *q = (const char *)(base + (size_t)(s >> 1) * row) + off + 8 * (s & 1);
     Rec r;
-    r.t = *(const double *)q;
-    r.r1 = *(const double *)(q + 1024);
-    r.r2 = *(const double *)(q + 2048);
+    r.t = tsh[s];
+    r.r1 = *(const double *)q;
+    r.r2 = *(const double *)(q + 1024);
     return r;
   }
   // kGroup records from SNP s (a multiple of 2); rows beyond the data are clamped (their values are never used)
@@ -81,20 +88,20 @@ struct RecCol {
 static constexpr double kLn2 = 0.6931471805599453094;
 
 // ---- expm1 for x <= 0 ------------------------------------------------------------------------------------
-__device__ inline double em_tiny(double x, double xx) {  // |x| < 2^-7: x + x^2 (1/2 + ... + x^4/720), rel. err < 6e-17
+__device__ __forceinline__ double em_tiny(double x, double xx) {  // |x| < 2^-7: x + x^2 (1/2 + ... + x^4/720), rel. err < 6e-17
   double p = __builtin_fma(x, 1.0 / 720, 1.0 / 120);
   p = __builtin_fma(x, p, 1.0 / 24);
   p = __builtin_fma(x, p, 1.0 / 6);
   p = __builtin_fma(x, p, 0.5);
   return __builtin_fma(xx, p, x);
 }
-__device__ inline double em_tiny5(double x, double xx) {  // |x| < 2^-8: terms through x^5/120, abs. err < 5e-18
+__device__ __forceinline__ double em_tiny5(double x, double xx) {  // |x| < 2^-8: terms through x^5/120, abs. err < 5e-18
   double p = __builtin_fma(x, 1.0 / 120, 1.0 / 24);
   p = __builtin_fma(x, p, 1.0 / 6);
   p = __builtin_fma(x, p, 0.5);
   return __builtin_fma(xx, p, x);
 }
-__device__ inline double em_small(double x) {  // |x| < 2^-4: Taylor through x^10/10!
+__device__ __forceinline__ double em_small(double x) {  // |x| < 2^-4: Taylor through x^10/10!
   double p = 1.0 / 3628800;
   p = __builtin_fma(x, p, 1.0 / 362880);
   p = __builtin_fma(x, p, 1.0 / 40320);
@@ -106,7 +113,7 @@ __device__ inline double em_small(double x) {  // |x| < 2^-4: Taylor through x^1
   p = __builtin_fma(x, p, 0.5);
   return __builtin_fma(x * x, p, x);
 }
-__device__ inline double em_general(double x) {  // any x <= 0: exp by range reduction, minus one; exact 0 below -745
+__device__ __forceinline__ double em_general(double x) {  // any x <= 0: exp by range reduction, minus one; exact 0 below -745
   double xc = __builtin_fmax(x, -1000.0);
   double n = __builtin_rint(xc * 1.4426950408889634074);
   double r = __builtin_fma(n, -6.93147180369123816490e-01, xc);
@@ -181,7 +188,7 @@ __device__ inline LaneC make_lane(double a, double k2, double k1, double k0) {
 
 // m1 = expm1(-a t) alone (double-recombination model)
 template <int TIER>
-__device__ inline double m1_at(const LaneC &C, double t) {
+__device__ __forceinline__ double m1_at(const LaneC &C, double t) {
   double x = C.na * t;
   return TIER <= 0 ? em_tiny(x, x * x) : (TIER == 1 ? em_small(x) : em_general(x));
 }
@@ -191,7 +198,7 @@ struct Trans {
   double u, w;
 };
 template <int TIER>
-__device__ inline Trans trans_at(const LaneC &C, double t) {
+__device__ __forceinline__ Trans trans_at(const LaneC &C, double t) {
   Trans T;
   double x = C.na * t;
   if (TIER < 0) {
@@ -224,7 +231,7 @@ __device__ inline Trans trans_at(const LaneC &C, double t) {
 //   new1 = f1 + u (f0 + f2 - f1 (r10 + r12)) = f1 - u (A + D),  A = f1 r10 - f0,  D = f1 r12 - f2
 //   new2 = f2 + u (f1 r12 - f2) - w (f2 k0 - f0 k2)
 template <int NV, bool DR, int TIER>
-__device__ inline void fwd_step(const LaneC &C, const Rec &r, double (&x)[NV][3]) {
+__device__ __forceinline__ void fwd_step(const LaneC &C, const Rec &r, double (&x)[NV][3]) {
   if (DR) {
     double m1 = m1_at<TIER>(C, r.t);  // T_xy = (1 - e1) k_y + [x == y] e1
 #pragma unroll
@@ -233,7 +240,7 @@ __device__ inline void fwd_step(const LaneC &C, const Rec &r, double (&x)[NV][3]
       double g0 = __builtin_fma(-C.k0, F, x[v][0]), g1 = __builtin_fma(-C.k1, F, x[v][1]),
              g2 = __builtin_fma(-C.k2, F, x[v][2]);
       x[v][0] = __builtin_fma(m1, g0, x[v][0]);
-      x[v][1] = __builtin_fma(m1, g1, x[v][1]) * r.r1;
+      x[v][1] = __builtin_fma(m1, g1, x[v][1]) * __builtin_fabs(r.r1);
       x[v][2] = __builtin_fma(m1, g2, x[v][2]) * r.r2;
     }
     return;
@@ -249,15 +256,15 @@ __device__ inline void fwd_step(const LaneC &C, const Rec &r, double (&x)[NV][3]
     double u1 = __builtin_fma(-T.u, A + D, f1);  // f0 + f2 - f1 (r10 + r12) = -(A + D): the columns of T - I sum to zero
     double u2 = __builtin_fma(-T.w, B, __builtin_fma(T.u, D, f2));
     x[v][0] = u0;
-    x[v][1] = u1 * r.r1;
+    x[v][1] = u1 * __builtin_fabs(r.r1);  // a dropped SNP carries r1 = -1
     x[v][2] = u2 * r.r2;
   }
 }
 
 // b <- T (S o b) (backward step through the record of the LATER SNP):  n_x = q_x + sum_{y != x} T_xy (q_y - q_x)
 template <bool DR, int TIER>
-__device__ inline void bwd_step(const LaneC &C, const Rec &r, double &b0, double &b1, double &b2) {
-  double q0 = b0, q1 = r.r1 * b1, q2 = r.r2 * b2;
+__device__ __forceinline__ void bwd_step(const LaneC &C, const Rec &r, double &b0, double &b1, double &b2) {
+  double q0 = b0, q1 = __builtin_fabs(r.r1) * b1, q2 = r.r2 * b2;
   if (DR) {
     double m1 = m1_at<TIER>(C, r.t);
     double G = __builtin_fma(C.k2, q2, __builtin_fma(C.k1, q1, C.k0 * q0));  // sum_y k_y q_y
@@ -275,7 +282,7 @@ __device__ inline void bwd_step(const LaneC &C, const Rec &r, double &b0, double
 }
 
 // exact rescale of a 3-vector by a power of two; returns the exponent removed (0 for an all-zero vector)
-__device__ inline int rescale3(double &x0, double &x1, double &x2) {
+__device__ __forceinline__ int rescale3(double &x0, double &x1, double &x2) {
   double m = __builtin_fmax(x0, __builtin_fmax(x1, x2));
   int e = (m > 0) ? __builtin_amdgcn_frexp_exp(m) : 0;
   x0 = __builtin_amdgcn_ldexp(x0, -e);
@@ -298,7 +305,31 @@ struct LaneMap {
   __device__ inline int operator()(int l) const { return pair ? pair[l] : l / div; }
 };
 
-__device__ inline bool rec_dropped(const Rec &r) { return __builtin_signbit(r.t); }
+__device__ inline bool rec_dropped(const Rec &r) { return __builtin_signbit(r.r1); }
+
+// The record as this lane must step through it: the shared distance, unless the record carries its own (sign bit of
+// r2: dropped -> |r2| is the distance and the emission is 1; kept -> distance 0 and |r2| is the emission).
+__device__ __forceinline__ Rec rec_lane(const Rec &r) {
+  Rec e;
+  const bool own = __builtin_signbit(r.r2), dropped = __builtin_signbit(r.r1);
+  e.t = own ? (dropped ? __builtin_fabs(r.r2) : 0.0) : r.t;
+  e.r1 = r.r1;
+  e.r2 = (own && dropped) ? 1.0 : __builtin_fabs(r.r2);
+  return e;
+}
+// does any lane of the wave hold a record with a distance of its own among these?
+template <int N>
+__device__ __forceinline__ bool own_distance(const Rec (&R)[N]) {
+  int m = hi_word(R[0].r2);
+#pragma unroll
+  for (int u = 1; u < N; u++) m |= hi_word(R[u].r2);
+  return __builtin_amdgcn_ballot_w64(m < 0) != 0;
+}
+template <int N>
+__device__ __forceinline__ void rec_lane_all(const Rec (&R)[N], Rec (&E)[N]) {
+#pragma unroll
+  for (int u = 0; u < N; u++) E[u] = rec_lane(R[u]);
+}
 
 // wave-uniform tier of a group of N records: 0 if every lane has |a t| < 2^-7 for all of them, 1 if < 2^-4, else 2
 // (-1 below 2^-8 when LOW).  t is +0.0, -0.0 (dropped) or positive, so its order is the order of its high word as a
@@ -306,7 +337,7 @@ __device__ inline bool rec_dropped(const Rec &r) { return __builtin_signbit(r.t)
 // per group); a t whose high word equals the limit's counts as above it, which only ever picks the more careful tier.
 // NaN has the largest high word and goes to tier 2, where it propagates.
 template <int N, bool LOW = false>
-__device__ inline int group_tier_h(int hlim0, int hlim1, int hlimm, const Rec (&R)[N]) {
+__device__ __forceinline__ int group_tier_h(int hlim0, int hlim1, int hlimm, const Rec (&R)[N]) {
   int hmax = hi_word(R[0].t);
 #pragma unroll
   for (int u = 1; u < N; u++) hmax = max(hmax, hi_word(R[u].t));
@@ -316,24 +347,24 @@ __device__ inline int group_tier_h(int hlim0, int hlim1, int hlimm, const Rec (&
   return 2;
 }
 template <int N, bool LOW = false>
-__device__ inline int group_tier(const LaneC &C, const Rec (&R)[N]) {
+__device__ __forceinline__ int group_tier(const LaneC &C, const Rec (&R)[N]) {
   return group_tier_h<N, LOW>(C.hlim0, C.hlim1, C.hlimm, R);
 }
 
 // one vector of one parameter point through one record (the NV = 1 case of fwd_step on a plain array)
 template <bool DR, int TIER>
-__device__ inline void fwd_step1(const LaneC &C, const Rec &r, double (&x)[3]) {
+__device__ __forceinline__ void fwd_step1(const LaneC &C, const Rec &r, double (&x)[3]) {
   double (&xv)[1][3] = *reinterpret_cast<double (*)[1][3]>(&x);
   fwd_step<1, DR, TIER>(C, r, xv);
 }
 
 template <int NV, bool DR, int TIER>
-__device__ inline void fwd_group_t(const LaneC &C, const Rec (&R)[kGroup], double (&x)[NV][3]) {
+__device__ __forceinline__ void fwd_group_t(const LaneC &C, const Rec (&R)[kGroup], double (&x)[NV][3]) {
 #pragma unroll
   for (int u = 0; u < kGroup; u++) fwd_step<NV, DR, TIER>(C, R[u], x);
 }
 template <int NV, bool DR>
-__device__ inline void fwd_group(const LaneC &C, const Rec (&R)[kGroup], double (&x)[NV][3]) {
+__device__ __forceinline__ void fwd_group(const LaneC &C, const Rec (&R)[kGroup], double (&x)[NV][3]) {
   int tier = group_tier<kGroup, !DR>(C, R);
   if (tier < 0) fwd_group_t<NV, DR, -1>(C, R, x);
   else if (tier == 0) fwd_group_t<NV, DR, 0>(C, R, x);
@@ -346,9 +377,13 @@ __device__ inline void fwd_group(const LaneC &C, const Rec (&R)[kGroup], double 
 // ring, so a wave always has (NBUF - 1) * 96 B per lane on the way from HBM while it computes: with 2-3 waves per SIMD
 // that covers the ~2 us loaded HBM latency.
 template <int NBUF, class FG, class FT>
-__device__ inline void stream_records(const RecCol &col, int sb, int se, int M, FG &&on_group, FT &&on_tail) {
+__device__ __forceinline__ void stream_records(const RecCol &col, int sb, int se, int M, FG &&on_group, FT &&on_tail) {
   constexpr int span = NBUF * kGroup;
   int s = sb;  // even: 0 or a chunk start
+  if (col.general) {  // record by record through the general-distance steps (rec_lane): rare, see kernels_emis.hpp
+    for (; s < se; s++) on_tail(col.at(s), s);
+    return;
+  }
   Rec buf[NBUF][kGroup];
   if (s + span <= se) {
 #pragma unroll
@@ -369,7 +404,7 @@ static constexpr int kNbufChunk = 2;
 
 // forward recursion over rows [sb, se) for NV vectors
 template <int NV, bool DR, int NBUF, class FC>
-__device__ inline void sweep(const RecCol &col, int sb, int se, int M, const LaneC &C, double (&x)[NV][3], int (&ex)[NV],
+__device__ __forceinline__ void sweep(const RecCol &col, int sb, int se, int M, const LaneC &C, double (&x)[NV][3], int (&ex)[NV],
                              FC &&at_tile) {
   stream_records<NBUF>(
       col, sb, se, M,
@@ -383,7 +418,7 @@ __device__ inline void sweep(const RecCol &col, int sb, int se, int M, const Lan
       },
       [&](const Rec &r, int s) {
         if ((s & 15) == 0) at_tile(s >> 4);
-        fwd_step<NV, DR, 2>(C, r, x);
+        fwd_step<NV, DR, 2>(C, rec_lane(r), x);
         if ((s & 7) == 7) {  // the tail can be NBUF * kGroup - 1 records long
 #pragma unroll
           for (int v = 0; v < NV; v++) ex[v] += rescale3(x[v][0], x[v][1], x[v][2]);
@@ -484,14 +519,14 @@ struct LaneSet {
 };
 
 template <int NV, bool DR, int TIER>
-__device__ inline void fwd_group_mp(const LaneSet<NV> &L, const Rec (&R)[kGroup], double (&x)[NV][3]) {
+__device__ __forceinline__ void fwd_group_mp(const LaneSet<NV> &L, const Rec (&R)[kGroup], double (&x)[NV][3]) {
 #pragma unroll
   for (int u = 0; u < kGroup; u++)
 #pragma unroll
     for (int v = 0; v < NV; v++) fwd_step1<DR, TIER>(L.C[v], R[u], x[v]);
 }
 template <int NV, bool DR, int TIER>
-__device__ inline void bwd_group_mp(const LaneSet<NV> &L, const Rec (&R)[kGroup], double (&b)[NV][3]) {
+__device__ __forceinline__ void bwd_group_mp(const LaneSet<NV> &L, const Rec (&R)[kGroup], double (&b)[NV][3]) {
 #pragma unroll
   for (int u = kGroup - 1; u >= 0; u--)
 #pragma unroll
@@ -500,7 +535,7 @@ __device__ inline void bwd_group_mp(const LaneSet<NV> &L, const Rec (&R)[kGroup]
 
 // forward half of a likelihood sweep: rows [sb, se) from x, exponents in L.norm
 template <bool DR, int NBUF, int NV>
-__device__ inline void like_forward(const RecCol &col, int sb, int se, int M, LaneSet<NV> &L, double (&x)[NV][3]) {
+__device__ __forceinline__ void like_forward(const RecCol &col, int sb, int se, int M, LaneSet<NV> &L, double (&x)[NV][3]) {
   auto renorm = [&]() {
 #pragma unroll
     for (int v = 0; v < NV; v++) L.norm[v](x[v][0], x[v][1], x[v][2]);
@@ -515,7 +550,8 @@ __device__ inline void like_forward(const RecCol &col, int sb, int se, int M, La
         else fwd_group_mp<NV, DR, 2>(L, R, x);
         if ((s & 12) == 12) renorm();  // every fourth group: 16 steps between renormalisations
       },
-      [&](const Rec &r, int s) {
+      [&](const Rec &r0, int s) {
+        const Rec r = rec_lane(r0);
 #pragma unroll
         for (int v = 0; v < NV; v++) fwd_step1<DR, 2>(L.C[v], r, x[v]);
         if ((s & 7) == 7) renorm();  // the tail can be NBUF * kGroup - 1 records long
@@ -529,7 +565,7 @@ __device__ inline void like_forward(const RecCol &col, int sb, int se, int M, La
 // waves NBUF 4; from three waves on NBUF 2, where a deeper ring would cost the third wave.
 template <bool DR, int NBUF, int NV>
 __global__ void __launch_bounds__(256)
-like_kernel(const double *__restrict__ rec, int M, int RP, LaneMap lane_pair, PairScale scale,
+like_kernel(const double *__restrict__ rec, const double *__restrict__ tsh, const int *__restrict__ own, int M, int RP, LaneMap lane_pair, PairScale scale,
             const double *__restrict__ params, int nslots, double alim1, double *__restrict__ out) {
   const int slot0 = (blockIdx.x * blockDim.x + threadIdx.x) * NV;
   if (slot0 >= nslots) return;
@@ -537,7 +573,7 @@ like_kernel(const double *__restrict__ rec, int M, int RP, LaneMap lane_pair, Pa
   double x[NV][3];
   L.init(params, slot0, nslots, alim1, DR, x);
   const int lp = lane_pair(slot0);
-  if (L.any) like_forward<DR, NBUF, NV>(RecCol(rec, RP, lp, M), 0, M, M, L, x);
+  if (L.any) like_forward<DR, NBUF, NV>(RecCol(rec, tsh, own, RP, lp, M), 0, M, M, L, x);
 #pragma unroll
   for (int v = 0; v < NV; v++) {
     if (slot0 + v >= nslots) break;
@@ -552,9 +588,13 @@ like_kernel(const double *__restrict__ rec, int M, int RP, LaneMap lane_pair, Pa
 // The same records from the last row down (the backward half of the two-sided likelihood): groups of kGroup rows
 // [base, base + kGroup) are handed over in descending order of base, then single rows down to sb.
 template <int NBUF, class FG, class FT>
-__device__ inline void stream_records_rev(const RecCol &col, int sb, int se, FG &&on_group, FT &&on_tail) {
+__device__ __forceinline__ void stream_records_rev(const RecCol &col, int sb, int se, FG &&on_group, FT &&on_tail) {
   constexpr int span = NBUF * kGroup;
   int s = se;  // rows [sb, s) are still to do
+  if (col.general) {
+    for (s = s - 1; s >= sb; s--) on_tail(col.at(s), s);
+    return;
+  }
   for (; (s & (kGroup - 1)) != 0 && s > sb; s--) on_tail(col.at(s - 1), s - 1);  // down to a group boundary
   Rec buf[NBUF][kGroup];
   if (s - span >= sb) {
@@ -572,7 +612,7 @@ __device__ inline void stream_records_rev(const RecCol &col, int sb, int se, FG 
 }
 
 template <bool DR, int TIER>
-__device__ inline void bwd_group_t(const LaneC &C, const Rec (&R)[kGroup], double &b0, double &b1, double &b2) {
+__device__ __forceinline__ void bwd_group_t(const LaneC &C, const Rec (&R)[kGroup], double &b0, double &b1, double &b2) {
 #pragma unroll
   for (int u = kGroup - 1; u >= 0; u--) bwd_step<DR, TIER>(C, R[u], b0, b1, b2);
 }
@@ -585,7 +625,7 @@ __device__ inline void bwd_group_t(const LaneC &C, const Rec (&R)[kGroup], doubl
 //
 template <bool DR, int NBUF, int NV>
 __global__ void __launch_bounds__(256)
-like_halves_kernel(const double *__restrict__ rec, int M, int RP, LaneMap lane_pair,
+like_halves_kernel(const double *__restrict__ rec, const double *__restrict__ tsh, const int *__restrict__ own, int M, int RP, LaneMap lane_pair,
                    const double *__restrict__ params, int nslots, int nsp, double alim1, double *__restrict__ part) {
   // nsp = slots padded to 256 NV: workgroups [0, nb) forward, [nb, 2 nb) backward; part is indexed by slot
   const int nb = nsp / (256 * NV);
@@ -597,7 +637,7 @@ like_halves_kernel(const double *__restrict__ rec, int M, int RP, LaneMap lane_p
   L.init(params, slot0, nslots, alim1, DR, x);
   if (!L.any) return;  // like_join_kernel rejects the points
   const int mid = (M / 2) & ~(kGroup - 1);
-  const RecCol col(rec, RP, lane_pair(slot0), M);
+  const RecCol col(rec, tsh, own, RP, lane_pair(slot0), M);
   if (!back) {
     like_forward<DR, NBUF, NV>(col, 0, mid, M, L, x);
 #pragma unroll
@@ -621,7 +661,8 @@ like_halves_kernel(const double *__restrict__ rec, int M, int RP, LaneMap lane_p
         else bwd_group_mp<NV, DR, 2>(L, R, x);
         if ((s & 12) == 0) renorm();
       },
-      [&](const Rec &r, int s) {
+      [&](const Rec &r0, int s) {
+        const Rec r = rec_lane(r0);
 #pragma unroll
         for (int v = 0; v < NV; v++) bwd_step<DR, 2>(L.C[v], r, x[v][0], x[v][1], x[v][2]);
         if ((s & 7) == 0) renorm();
@@ -678,7 +719,7 @@ struct TileCkpt {
 
 template <bool DR, bool CKPT>
 __global__ void __launch_bounds__(256)
-chunk_matrix_kernel(const double *__restrict__ rec, int M, int RP, LaneMap lane_pair,
+chunk_matrix_kernel(const double *__restrict__ rec, const double *__restrict__ tsh, const int *__restrict__ own, int M, int RP, LaneMap lane_pair,
                     const double *__restrict__ params, int nlanes, int nlp, int nchunk, int chunk_len, double alim1,
                     int reject, ChunkOut O, TileCkpt ck, int col0) {  // col0: first column of the block's pairs (CKPT)
   int bpc = nlp / 256;  // workgroups per chunk
@@ -692,7 +733,7 @@ chunk_matrix_kernel(const double *__restrict__ rec, int M, int RP, LaneMap lane_
   double x[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
   int ex[3] = {0, 0, 0};
   const int lp = lane_pair(l);
-  sweep<3, DR, kNbufChunk>(RecCol(rec, RP, col0 + lp, M), sb, se, M, C, x, ex, [&](int tile) {
+  sweep<3, DR, kNbufChunk>(RecCol(rec, tsh, own, RP, col0 + lp, M), sb, se, M, C, x, ex, [&](int tile) {
     if (CKPT) {
       double *qm = ck.m(tile, lp);
       int *qe = ck.e(tile, lp);
@@ -863,7 +904,7 @@ static constexpr int kTilePad = kTile + 1;
 static constexpr int kBwdThreads = 64;  // one wave per workgroup: 13.5 KiB of LDS each
 
 template <bool DR, int TIER>
-__device__ inline void dec_tile(const LaneC &C, const Rec (&R)[kTile], double f0, double f1, double f2, int tb, int te,
+__device__ __forceinline__ void dec_tile(const LaneC &C, const Rec (&R)[kTile], double f0, double f1, double f2, int tb, int te,
                                 double &b0, double &b1, double &b2, double (&tile)[3][kBwdThreads][kTilePad]) {
   constexpr int NG = kTile / kGroup;
   double G[NG][3];
@@ -935,7 +976,8 @@ __device__ inline double round_sig4(double x) {
 // double result rounded once to float.
 template <bool DR, typename OutT>
 __global__ void __launch_bounds__(kBwdThreads)
-decode_bwd_kernel(const double *__restrict__ rec, int M, int P, int RP, int col0, const double *__restrict__ params,
+decode_bwd_kernel(const double *__restrict__ rec, const double *__restrict__ tsh, const int *__restrict__ own, int M, int P, int RP, int col0,
+                  const double *__restrict__ params,
                   int nlp, int chunk_len, const double *__restrict__ astart, const double *__restrict__ bend,
                   TileCkpt ck, OutT *__restrict__ post, int rows, int sig4) {  // sig4: float rows rounded as the .post text
   __shared__ double tile[3][kBwdThreads][kTilePad];
@@ -955,7 +997,7 @@ decode_bwd_kernel(const double *__restrict__ rec, int M, int P, int RP, int col0
     a0 = astart[at]; a1 = astart[at + 1]; a2 = astart[at + 2];
     b0 = bend[at]; b1 = bend[at + 1]; b2 = bend[at + 2];
   }
-  const RecCol col(rec, RP, col0 + pc, M);
+  const RecCol col(rec, tsh, own, RP, col0 + pc, M);
   for (int tb = (se - 1) & ~(kTile - 1); tb >= sb; tb -= kTile) {
     int te = min(se, tb + kTile);
     Rec R[kTile];
@@ -973,10 +1015,16 @@ decode_bwd_kernel(const double *__restrict__ rec, int M, int P, int RP, int col0
     double f0 = a0, f1 = a1, f2 = a2;
     apply_chunk_fwd(f0, f1, f2, X);
     norm_fast(f0, f1, f2);
-    int tier = group_tier<kTile>(C, R);
-    if (tier == 0) dec_tile<DR, 0>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
-    else if (tier == 1) dec_tile<DR, 1>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
-    else dec_tile<DR, 2>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
+    if (col.general && own_distance(R)) {
+      Rec E[kTile];
+      rec_lane_all(R, E);
+      dec_tile<DR, 2>(C, E, f0, f1, f2, tb, te, b0, b1, b2, tile);
+    } else {
+      int tier = group_tier<kTile>(C, R);
+      if (tier == 0) dec_tile<DR, 0>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
+      else if (tier == 1) dec_tile<DR, 1>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
+      else dec_tile<DR, 2>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
+    }
     __syncthreads();
     // 3 x 64 x kTile values; consecutive threads write consecutive SNPs of one pair row (128-byte pieces)
 #pragma unroll 12

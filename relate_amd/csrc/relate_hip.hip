@@ -159,10 +159,13 @@ struct relate_hip_ctx {
   int Wt = 0;
   bool winMode = false;      // stage_pairs_win_kernel + depth table (back2 <= 32)
   DBuf<double> dPos, dMaf, dMea, dPBA, dPbA, dPBa, dPba, dTab1, dTabL, dTabD;
+  DBuf<double> dTsh;       // shared distances tsh[s] = pos[s] - pos[s-1] (negative: 1e7; tsh[0] = 0), M + 2 entries
+  DBuf<int> dBnd;          // chromosome breaks: the SNPs s with pos[s] < pos[s-1]
+  int nBnd = 0;
   DBuf<int> dChoose;
   DBuf<uint8_t> dOrder;  // per-SNP preference order of the conditioning depths (windowed staging)
   // device: staged pair block
-  DBuf<double> dRec;            // staged records (t, S1/S0, S2/S0; layout: kernels_emis.hpp), padded pair count recPitch
+  DBuf<double> dRec;            // staged records (S1/S0, S2/S0; layout: kernels_emis.hpp), padded pair count recPitch
   DBuf<double> dRecV;           // the full format (t, S0, S1, S2) of a block: Viterbi and inspection only
   DBuf<int32_t> dPairs;
   std::vector<int32_t> staged;  // pairs of the block currently in dRec (2 ints per pair)
@@ -171,6 +174,7 @@ struct relate_hip_ctx {
   DBuf<double> dScM, dPairM;    // the factor taken out of the records: per-run partial products, per-pair result
   DBuf<int> dScE, dScN, dPairE; // ... exponents, kept-SNP counts
   DBuf<int> dNsnp;              // SNPs kept per pair of the staged block
+  DBuf<int> dPairOwn;           // per column: 1 if the pair has records that carry their own distance (boundary_fixup_kernel)
   std::vector<int> h_nsnp;      // the same on the host
   // device: work
   DBuf<int32_t> dLanePair;
@@ -386,6 +390,15 @@ int stage_cols(relate_hip_t h, const int32_t *pairs, int n, int col0, int RP, bo
   }
   HIPCHK(h, hipGetLastError());
   if (!full) {
+    HIPCHK(h, hipMemsetAsync(h->dPairOwn.p + col0, 0, sizeof(int) * n, h->stream));
+    if (h->nBnd > 0) {  // runs of dropped SNPs across a chromosome break (kernels_emis.hpp)
+      hipLaunchKernelGGL(boundary_fixup_kernel, dim3(blocks_for((long)n * h->nBnd, 256)), dim3(256), 0, h->stream,
+                         h->dG.p, h->M, h->W, h->dPairs.p, n, h->dBnd.p, h->nBnd, h->dPos.p, R.p, RP, col0,
+                         h->dPairOwn.p);
+      HIPCHK(h, hipGetLastError());
+    }
+  }
+  if (!full) {
     hipLaunchKernelGGL(scale_reduce_kernel, dim3(blocks_for(n, 64)), dim3(64 * kScaleSeg), 0, h->stream, h->dScM.p,
                        h->dScE.p, h->dScN.p, nruns, RP, col0, n, h->dPairM.p, h->dPairE.p, h->dNsnp.p);
     HIPCHK(h, hipGetLastError());
@@ -421,6 +434,7 @@ int stage_block(relate_hip_t h, const int32_t *pairs, int P, bool full = false) 
     HIPCHK(h, h->dPairM.ensure(RP));
     HIPCHK(h, h->dPairE.ensure(RP));
     HIPCHK(h, h->dNsnp.ensure(RP));
+    HIPCHK(h, h->dPairOwn.ensure(RP));
     h->h_nsnp.resize(P);
   }
   int rc = stage_cols(h, pairs, P, 0, RP, full);
@@ -555,7 +569,7 @@ int launch_like(relate_hip_t h, int nl, const LikeIO &io) {
       dim3 grid((unsigned)(2 * (nsp / (256 * NV))));
       const bool shallow = lanes > simd_lanes;
 #define LAUNCH_HALVES(DR, NB, NVV)                                                                                     \
-  hipLaunchKernelGGL((like_halves_kernel<DR, NB, NVV>), grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch,   \
+  hipLaunchKernelGGL((like_halves_kernel<DR, NB, NVV>), grid, dim3(256), 0, h->stream, h->dRec.p, h->dTsh.p, h->dPairOwn.p, h->M, h->recPitch,   \
                      io.map, io.params, nl, nsp, h->o.alim[1], part)
       if (dr) {
         if (NV == 2) LAUNCH_HALVES(true, 4, 2);
@@ -576,7 +590,7 @@ int launch_like(relate_hip_t h, int nl, const LikeIO &io) {
     const int nbuf = lanes <= simd_lanes ? 6 : (lanes <= 2 * simd_lanes ? 4 : 2);
     dim3 grid(blocks_for(lanes, 256)), block(256);
 #define LAUNCH_LIKE(DR, NB, NVV)                                                                                   \
-  hipLaunchKernelGGL((like_kernel<DR, NB, NVV>), grid, block, 0, h->stream, h->dRec.p, h->M, h->recPitch, io.map, \
+  hipLaunchKernelGGL((like_kernel<DR, NB, NVV>), grid, block, 0, h->stream, h->dRec.p, h->dTsh.p, h->dPairOwn.p, h->M, h->recPitch, io.map, \
                      scale, io.params, nl, h->o.alim[1], io.out)
 #define LAUNCH_LIKE_NV(DR)                                      \
   do {                                                          \
@@ -607,10 +621,10 @@ int launch_like(relate_hip_t h, int nl, const LikeIO &io) {
   }
   dim3 grid((unsigned)((size_t)(nlp / 256) * nchunk));
   if (dr)
-    hipLaunchKernelGGL((chunk_matrix_kernel<true, false>), grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch,
+    hipLaunchKernelGGL((chunk_matrix_kernel<true, false>), grid, dim3(256), 0, h->stream, h->dRec.p, h->dTsh.p, h->dPairOwn.p, h->M, h->recPitch,
                        io.map, io.params, nl, nlp, nchunk, clen, h->o.alim[1], 1, O, TileCkpt{nullptr, 0}, 0);
   else
-    hipLaunchKernelGGL((chunk_matrix_kernel<false, false>), grid, dim3(256), 0, h->stream, h->dRec.p, h->M, h->recPitch,
+    hipLaunchKernelGGL((chunk_matrix_kernel<false, false>), grid, dim3(256), 0, h->stream, h->dRec.p, h->dTsh.p, h->dPairOwn.p, h->M, h->recPitch,
                        io.map, io.params, nl, nlp, nchunk, clen, h->o.alim[1], 1, O, TileCkpt{nullptr, 0}, 0);
   HIPCHK(h, hipGetLastError());
   hipLaunchKernelGGL(like_combine_kernel, dim3(blocks_for(nl, 256)), dim3(256), 0, h->stream, O, io.map, scale,
@@ -1244,10 +1258,10 @@ int launch_decode(relate_hip_t h, int p0, int P, int f32_rows = 0, int sig4 = 0)
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   dim3 grid((unsigned)((size_t)(nlp / 256) * nchunk));
   if (dr)
-    hipLaunchKernelGGL((chunk_matrix_kernel<true, true>), grid, dim3(256), 0, h->stream, rec, M, RP, LaneMap{nullptr, 1},
+    hipLaunchKernelGGL((chunk_matrix_kernel<true, true>), grid, dim3(256), 0, h->stream, rec, h->dTsh.p, h->dPairOwn.p, M, RP, LaneMap{nullptr, 1},
                        h->dParams.p, P, nlp, nchunk, clen, h->o.alim[1], 0, O, ck, p0);
   else
-    hipLaunchKernelGGL((chunk_matrix_kernel<false, true>), grid, dim3(256), 0, h->stream, rec, M, RP, LaneMap{nullptr, 1},
+    hipLaunchKernelGGL((chunk_matrix_kernel<false, true>), grid, dim3(256), 0, h->stream, rec, h->dTsh.p, h->dPairOwn.p, M, RP, LaneMap{nullptr, 1},
                        h->dParams.p, P, nlp, nchunk, clen, h->o.alim[1], 0, O, ck, p0);
   HIPCHK(h, hipGetLastError());
   if (nchunk > 1) {
@@ -1262,7 +1276,7 @@ int launch_decode(relate_hip_t h, int p0, int P, int f32_rows = 0, int sig4 = 0)
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
   dim3 bgrid((unsigned)((size_t)((P + kBwdThreads - 1) / kBwdThreads) * nchunk));
 #define LAUNCH_BWD(DRV, T, OUT, ROWS)                                                                              \
-  hipLaunchKernelGGL((decode_bwd_kernel<DRV, T>), bgrid, dim3(kBwdThreads), 0, h->stream, rec, M, P, RP, p0,         \
+  hipLaunchKernelGGL((decode_bwd_kernel<DRV, T>), bgrid, dim3(kBwdThreads), 0, h->stream, rec, h->dTsh.p, h->dPairOwn.p, M, P, RP, p0, \
                      h->dParams.p, nlp, clen, astart, bend, ck, OUT, ROWS, sig4)
   if (f32_rows) {
     float *pf = reinterpret_cast<float *>(h->dPost.p);
@@ -1374,6 +1388,7 @@ int relate_hip_create(relate_hip_t *out, int device_id) {
 int relate_hip_destroy(relate_hip_t h) {
   if (!h) return RELATE_OK;
   (void)hipSetDevice(h->dev);
+  h->dTsh.release(); h->dBnd.release(); h->dPairOwn.release();
   h->dG.release(); h->dPos.release(); h->dMaf.release(); h->dMea.release(); h->dPBA.release(); h->dPbA.release();
   h->dPBa.release(); h->dPba.release(); h->dTab1.release(); h->dTabL.release(); h->dChoose.release();
   h->dGt.release(); h->dTabD.release(); h->dOrder.release();
@@ -1639,6 +1654,19 @@ int relate_hip_precalc(relate_hip_t h, int *keep_out, int *M_out) {
   for (int s = 0; s < M; s++) h->h_pos[s] = h->h_pos_raw[cols[s]];
   PCHK(h->dPos.ensure(M));
   PCHK(hipMemcpyAsync(h->dPos.p, h->h_pos.data(), sizeof(double) * M, hipMemcpyHostToDevice, st));
+  std::vector<double> tsh((size_t)M + 2, 0.0);  // diff (:391-404) on consecutive SNPs
+  std::vector<int> bnd;
+  for (int s = 1; s < M; s++) {
+    double d = h->h_pos[s] - h->h_pos[s - 1];
+    if (d < 0) { d = 10000000.0; bnd.push_back(s); }
+    tsh[s] = d;
+  }
+  PCHK(h->dTsh.ensure(tsh.size()));
+  PCHK(hipMemcpyAsync(h->dTsh.p, tsh.data(), sizeof(double) * tsh.size(), hipMemcpyHostToDevice, st));
+  h->nBnd = (int)bnd.size();
+  PCHK(h->dBnd.ensure(std::max<size_t>(1, bnd.size())));
+  if (!bnd.empty()) PCHK(hipMemcpyAsync(h->dBnd.p, bnd.data(), sizeof(int) * bnd.size(), hipMemcpyHostToDevice, st));
+  PCHK(hipStreamSynchronize(st));  // the host vectors go out of scope
   PCHK(h->dMaf.ensure(M));
   hipLaunchKernelGGL(maf_kernel, dim3(blocks_for(M, 256)), dim3(256), 0, st, Gfinal, M, W, h->dMaf.p);
   PCHK(hipGetLastError());

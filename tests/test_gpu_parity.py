@@ -576,3 +576,55 @@ def test_full_size_properties_config4():
         assert (post[n][:, ~miss] >= 0).all()
         assert ns[n] == int((~miss).sum())
     assert (post[1][0][post[1][0] != -1] == 0).all()
+
+
+def test_dropped_run_across_a_chromosome_break_with_a_non_negative_distance(oracle, monkeypatch):
+    """The records carry no distance: every SNP steps by the shared pos[s] - pos[s-1] and the steps over dropped SNPs
+    compose (T(t1) T(t2) = T(t1 + t2)).  One case does not compose: a run of dropped SNPs across a chromosome break whose
+    kept ends lie a NON-negative distance apart -- the reference then steps by that distance (diff, src/relateHMM.cpp:
+    391-404, looks only at the sign), not by the break's 1e7.  boundary_fixup_kernel marks such runs and the sweeps take
+    the per-lane-distance path for them.  Data: two chromosomes, the second one's first SNP at 0.005 and its others
+    beyond the end of the first; individual 0 misses the first SNP of chromosome 2 (run of 1), individual 1 misses
+    SNPs 998..1003 (run of 6 across the break), individual 2 misses 995..999 (run ends AT the break: composes, no
+    mark).  Likelihood (single sweep, two-sided, and cut along the SNP axis) and posteriors against the oracle, which
+    follows the reference's per-pair distances."""
+    import relate_amd
+    from relate_amd import synth
+    N, M = 12, 2000
+    g, pos, chr_, _ = synth.make_dataset(N, M, nchr=1, n_related=2, seed=5)
+    g = g.copy()
+    pos = np.concatenate([0.01 * np.arange(1, 1001), [0.005], 10.5 + 0.01 * np.arange(1, 1000)])
+    chr_ = np.concatenate([np.ones(1000, dtype=np.int32), 2 * np.ones(1000, dtype=np.int32)])
+    g[g == 0] = 1
+    g[10, :] = 1                             # one homozygote of each kind: every SNP passes the MAF filter
+    g[11, :] = 3
+    g[0, 1000] = 0
+    g[1, 998:1004] = 0
+    g[2, 995:1000] = 0
+    opt = dict(pc.options("options.all.pair.txt"))
+    p = pc.oracle_precalc(oracle, g, pos, opt)
+    assert p["keep"].all()
+    pairs = [(0, 3), (1, 3), (0, 1), (2, 3), (3, 4), (1, 2)]
+    pars = np.array([(0.05, 0.2, 0.3), (0.1, 0.0, 0.4), (0.02, 0.3, 0.5), (0.08, 0.1, 0.6)])
+    want_like, want_post, idxs = [], [], []
+    for (i, j) in pairs:
+        st = pc.oracle_stage(oracle, p, opt, i, j)
+        idxs.append(np.where(st["keep"] == 1)[0])
+        want_like.append([oracle.like(d, *st["Sk"], st["t"], 0, opt["alim1"]) for d in pars])
+        want_post.append(oracle.decode(pars[0], *st["Sk"], st["t"], 0))
+    # the distances the reference uses across the break for the marked pairs: +0.51 / +0.56, not 1e7
+    st = pc.oracle_stage(oracle, p, opt, 0, 3)
+    assert abs(st["t"][1000] - (pos[1001] - pos[999])) < 1e-12
+    for lanes in ("1", "1000000"):           # single / two-sided sweeps; cut along the SNP axis
+        monkeypatch.setenv("RELATE_SINGLE_SWEEP_LANES", lanes)
+        H = relate_amd.Relate(0)
+        H.init_globals(g, pos, chr_, opt)
+        got = H.like(pairs, np.broadcast_to(pars, (len(pairs),) + pars.shape).copy())
+        np.testing.assert_allclose(got, want_like, rtol=1e-10)
+        post, _, ns = H.decode(pairs, np.broadcast_to(pars[0], (len(pairs), 3)).copy())
+        for n in range(len(pairs)):
+            assert ns[n] == len(idxs[n])
+            np.testing.assert_allclose(post[n][:, idxs[n]], want_post[n], atol=1e-8)
+            dropped = np.setdiff1d(np.arange(M), idxs[n])
+            assert (post[n][:, dropped] == -1).all()
+        H.close()

@@ -38,9 +38,9 @@ for sh in a.shapes:
     st = H.timings()["stage_ms"]
     ms = H.bench_like(blk, par, a.reps)
     line = "P=%d E=%d M=%d lanes=%d  stage %.2f ms (%.0f GB/s)  like %.3f ms  %.1f G lane-steps/s  rec-read %.0f GB/s" % (
-        P, E, M, P * E, st, 32.5 * P * M / st / 1e6 if st else 0, ms, P * E * M / ms / 1e6, 32.0 * P * M / ms / 1e6)
+        P, E, M, P * E, st, 16.75 * P * M / st / 1e6 if st else 0, ms, P * E * M / ms / 1e6, 16.0 * P * M / ms / 1e6)
     if a.decode:
         f, b = H.bench_decode(blk, np.ascontiguousarray(par[:, 0, :]), a.reps)
         line += "  dec_fwd %.2f ms (%.0f GB/s) dec_bwd %.2f ms (%.0f GB/s)" % (
-            f, 56.0 * P * M / f / 1e6, b, 80.0 * P * M / b / 1e6)
+            f, 21.25 * P * M / f / 1e6, b, 45.25 * P * M / b / 1e6)
     print(line, flush=True)
