@@ -186,16 +186,16 @@ def cpu_baseline_threads(H, opt, E, want_seconds=6.0):
                 sum(done), Ms, E, nt, dt)}
 
 
-def fit_leg(H, allp, npairs, M):
+def fit_leg(H, allp, npairs, M, first=0, note=None):
     """Outside the timed region and not part of `value`: the whole estimation (relate_hip_fit: up to 8 restarts of the
     2-parameter L-BFGS-B search per pair, every objective value a likelihood sweep on the GPU) on the first pairs of the
     same data set, wall-clock around the C-ABI call -- what a user of the all-pairs scan waits for."""
-    blk = allp[:npairs]
+    blk = allp[first:first + npairs]
     # The record buffer grows to this block size once per process (a scan fits hundreds of blocks with it): grow it on
     # another block of the same size first and report that time on its own.
     t0 = time.perf_counter()
-    if len(allp) >= 2 * npairs:
-        H.bench_like(allp[npairs:2 * npairs], eval_points(npairs, 1), 1)
+    if len(allp) >= first + 2 * npairs:
+        H.bench_like(allp[first + npairs:first + 2 * npairs], eval_points(npairs, 1), 1)
     t_grow = time.perf_counter() - t0
     t0 = time.perf_counter()
     res = H.fit(blk)
@@ -215,9 +215,9 @@ def fit_leg(H, allp, npairs, M):
             "launches": {"sweep": st["sweep_launches"], "chunked": st["chunked_launches"],
                          "sweep_ms": st["sweep_ms"], "chunked_ms": st["chunked_ms"],
                          "sweep_lane_steps": st["sweep_point_steps"], "chunked_lane_steps": st["chunked_point_steps"]},
-            "note": "relate_hip_fit, options.all.pair.txt semantics (calcA, timesToRun 8: the 2-parameter mode whose estimates "
-                    "the reference itself does not reproduce across seeds, so its outputs are validated to -logL within 2e-3 only); "
-                    "not part of value"}
+            "note": note or "relate_hip_fit, options.all.pair.txt semantics (calcA, timesToRun 8: the 2-parameter mode whose "
+                    "estimates the reference itself does not reproduce across seeds, so its outputs are validated to -logL within "
+                    "2e-3 only); not part of value"}
 
 
 def opts_linkage():
@@ -415,6 +415,13 @@ def main():
             line["linkage_mode"] = linkage_leg(local, args.inds, args.snps, all_pairs, min(args.linkage_pairs, len(all_pairs)))
         if world == 1 and not args.no_cpu and not args.no_fit:
             line["fit"] = fit_leg(H, mine, min(args.fit_pairs, len(mine)), M)
+            if args.fit_pairs > 0 and len(mine) >= 3 * args.fit_pairs + 4 * args.fit_pairs:
+                # what a scan's later blocks run at: a block of the size the records allow (twice the first one here), on
+                # the same handle, which has seen that first waves of restarts do not settle pairs in this mode
+                line["fit_next_block"] = fit_leg(H, mine, 2 * args.fit_pairs, M, first=3 * args.fit_pairs,
+                                                 note="the next block of the same scan, twice the pairs: all restarts of a "
+                                                      "pair start together from the first round (the handle's previous fit saw "
+                                                      "that first waves do not settle pairs); not part of value")
         if world == 1 and not args.no_cpu and not args.no_baseline:
             line["cpu_baseline"] = cpu_baseline(H, opt, E)
             line["cpu_baseline_all_cores"] = cpu_baseline_threads(H, opt, E)

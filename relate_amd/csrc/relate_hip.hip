@@ -1106,7 +1106,9 @@ int fit_block(relate_hip_t h, int P, long pair_base, const double *starts, relat
   // Each population should still fill whole turns of the machine on its own (a few runs of 3-5 lanes per pair), or the
   // split costs more likelihood time than the overlap saves: 8 192 pairs x 5e5 SNPs ran 13.0 s unsplit, 15.6 s split;
   // 44 850 pairs x 5e4 SNPs 15.6 s unsplit, 9.7 s split.  RELATE_FIT_POPULATIONS = 1 | 2 overrides (tests, tuning).
-  int npop = P >= 16384 ? 2 : 1;
+  // With rows of 5e5 SNPs the host's share of a round is ~6 % (runs in recycled slabs, persistent workers) and one
+  // population's larger launches win: 16 384 pairs 15.8 s unsplit, 16.7 s split; rows below ~1.5e5 SNPs still split.
+  int npop = (P >= 16384 && h->M < 150000) ? 2 : 1;
   if (const char *e = getenv("RELATE_FIT_POPULATIONS")) npop = atoi(e) >= 2 && P >= 2 ? 2 : 1;
   FitPop pop[2];
   const std::vector<int32_t> blk(h->staged);  // the block's pairs by column (compaction clears the memo)
@@ -1468,14 +1470,31 @@ int relate_hip_load(relate_hip_t h, const uint8_t *geno, int N, int M_raw, const
   if (opts->doPrune && opts->back == 0)
     return fail(h, RELATE_E_ARG, "Must supply a back > 0, when you want to prune (src/runRelate.cpp:89-92)");
   if (opts->back < 0) return fail(h, RELATE_E_ARG, "back must be >= 0");
-  for (size_t i = 0; i < (size_t)N * M_raw; i++)
-    if (geno[i] > 3) return fail(h, RELATE_E_ARG, "Error in genotype data: value should be between 0 and 3");
+  {  // one threaded pass: copy and validate (the host keeps the matrix for relate_hip_precalc)
+    const size_t total = (size_t)N * M_raw;
+    h->h_raw.resize(total);
+    std::atomic<bool> bad{false};
+    uint8_t *dst = h->h_raw.data();
+    parallel_for(total, [&](size_t lo, size_t hi) {
+      uint8_t worst = 0;
+      for (size_t i = lo; i < hi; i++) {
+        const uint8_t v = geno[i];
+        dst[i] = v;
+        worst |= v;
+      }
+      if (worst > 3) bad.store(true);
+    }, (size_t)1 << 20);
+    if (bad.load()) {
+      h->h_raw.clear();
+      h->loaded = false;
+      return fail(h, RELATE_E_ARG, "Error in genotype data: value should be between 0 and 3");
+    }
+  }
   h->o = *opts;
   h->back2 = 2 * opts->back;  // post_processing_of_option_pars, src/runRelate.cpp:88
   h->N = N;
   h->Mraw = M_raw;
   h->W = (N + 31) / 32;
-  h->h_raw.assign(geno, geno + (size_t)N * M_raw);
   h->h_bed.clear();
   h->h_bed.shrink_to_fit();
   h->h_bedcols.clear();
