@@ -1103,48 +1103,113 @@ __device__ inline void ref_trans_at(const RefTrans &C, double t, double (&T)[3][
   T[2][1] = t01; T[2][0] = t20; T[2][2] = (-t01 - t20) + 1;
 }
 
+// A workgroup takes kVitPairs pairs.  The expensive part of a step -- two exponentials and twelve logarithms, none of
+// which depends on the chain -- is done by all 256 threads for a tile of kVitTile SNPs at once (thread = one pair and one
+// SNP of the tile) and left in LDS; then one lane per pair walks the tile: nine adds, the max3 / which_max rules, one
+// back-pointer byte per SNP (0xFF = SNP dropped for the pair).  The same library calls on the same arguments as one lane
+// per pair would make, so the values, the ties and the paths are the same.  bp: (M + 1) x P bytes; row M holds the
+// state the path ends in (0xFF: the pair has no kept SNP).
+static constexpr int kVitPairs = 16, kVitTile = 16;
 __global__ void __launch_bounds__(256)
-viterbi_kernel(const double *__restrict__ rec, int M, int P, int RP, const double *__restrict__ params, int double_recom,
-               uint8_t *__restrict__ bp, int8_t *__restrict__ path) {  // rec: the FULL format (t, S0, S1, S2 planes)
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  double a = params[3 * p], k2 = params[3 * p + 1], k1 = params[3 * p + 2];
-  double k0 = 1 - k2 - k1;
-  RefTrans C = make_ref_trans(a, k2, k1, k0, double_recom);
-  double v0 = 0, v1 = 0, v2 = 0;
+viterbi_fwd_kernel(const double *__restrict__ rec, int M, int P, int RP, const double *__restrict__ params,
+                   int double_recom, uint8_t *__restrict__ bp) {  // rec: the FULL format (t, S0, S1, S2 planes)
+  __shared__ double lg[kVitTile][12][kVitPairs + 1];
+  __shared__ unsigned char dropped[kVitTile][kVitPairs];
+  const int pp = threadIdx.x % kVitPairs, ss = threadIdx.x / kVitPairs;
+  const int p = blockIdx.x * kVitPairs + pp;
+  const int pc = p < P ? p : P - 1;  // dead lanes shadow a valid pair and write nothing
+  const double a = params[3 * pc], k2 = params[3 * pc + 1], k1 = params[3 * pc + 2];
+  const double k0 = 1 - k2 - k1;
+  const RefTrans C = make_ref_trans(a, k2, k1, k0, double_recom);
+  double v0 = 0, v1 = 0, v2 = 0;  // the walking lanes' chain (threads with ss == 0)
   bool started = false;
-  for (int s = 0; s < M; s++) {
-    const double *row = rec + rec_off(s, p, kRecPlanesFull, RP);
-    const double rt = row[0];
-    if (__builtin_signbit(rt)) continue;
-    double l0 = log(row[128]), l1 = log(row[256]), l2 = log(row[384]);
-    if (!started) {
-      double mx = fmax(log(k0), fmax(log(k1), log(k2)));
-      v0 = mx + l0; v1 = mx + l1; v2 = mx + l2;
-      started = true;
-      bp[(size_t)s * P + p] = 0;
-    } else {
-      double T[3][3];
-      ref_trans_at(C, rt, T);
-      double L[3][3];
-      for (int x = 0; x < 3; x++)
-        for (int y = 0; y < 3; y++) L[x][y] = log(T[x][y]);
-      double n0 = l0 + vmax3(L[0][0] + v0, L[1][0] + v1, L[2][0] + v2);
-      double n1 = l1 + vmax3(L[0][1] + v0, L[1][1] + v1, L[2][1] + v2);
-      double n2 = l2 + vmax3(L[0][2] + v0, L[1][2] + v1, L[2][2] + v2);
-      int w0 = vwhich3(v0 + L[0][0], v1 + L[1][0], v2 + L[2][0]);
-      int w1 = vwhich3(v0 + L[0][1], v1 + L[1][1], v2 + L[2][1]);
-      int w2 = vwhich3(v0 + L[0][2], v1 + L[1][2], v2 + L[2][2]);
-      bp[(size_t)s * P + p] = (uint8_t)(w0 | (w1 << 2) | (w2 << 4));
-      v0 = n0; v1 = n1; v2 = n2;
+  for (int s0 = 0; s0 < M; s0 += kVitTile) {
+    const int s = s0 + ss;
+    if (s < M) {
+      const double *row = rec + rec_off(s, pc, kRecPlanesFull, RP);
+      const double rt = row[0];
+      const bool dr = __builtin_signbit(rt);
+      dropped[ss][pp] = dr ? 1 : 0;
+      if (!dr) {
+        lg[ss][0][pp] = log(row[128]); lg[ss][1][pp] = log(row[256]); lg[ss][2][pp] = log(row[384]);
+        double T[3][3];
+        ref_trans_at(C, rt, T);
+#pragma unroll
+        for (int x = 0; x < 3; x++)
+#pragma unroll
+          for (int y = 0; y < 3; y++) lg[ss][3 + x * 3 + y][pp] = log(T[x][y]);
+      }
     }
+    __syncthreads();
+    if (ss == 0 && p < P) {
+      const int n = min(kVitTile, M - s0);
+      for (int u = 0; u < n; u++) {
+        uint8_t b = 0xFF;
+        if (!dropped[u][pp]) {
+          const double l0 = lg[u][0][pp], l1 = lg[u][1][pp], l2 = lg[u][2][pp];
+          if (!started) {
+            double mx = fmax(log(k0), fmax(log(k1), log(k2)));
+            v0 = mx + l0; v1 = mx + l1; v2 = mx + l2;
+            started = true;
+            b = 0;
+          } else {
+            double L[3][3];
+#pragma unroll
+            for (int x = 0; x < 3; x++)
+#pragma unroll
+              for (int y = 0; y < 3; y++) L[x][y] = lg[u][3 + x * 3 + y][pp];
+            double n0 = l0 + vmax3(L[0][0] + v0, L[1][0] + v1, L[2][0] + v2);
+            double n1 = l1 + vmax3(L[0][1] + v0, L[1][1] + v1, L[2][1] + v2);
+            double n2 = l2 + vmax3(L[0][2] + v0, L[1][2] + v1, L[2][2] + v2);
+            int w0 = vwhich3(v0 + L[0][0], v1 + L[1][0], v2 + L[2][0]);
+            int w1 = vwhich3(v0 + L[0][1], v1 + L[1][1], v2 + L[2][1]);
+            int w2 = vwhich3(v0 + L[0][2], v1 + L[1][2], v2 + L[2][2]);
+            b = (uint8_t)(w0 | (w1 << 2) | (w2 << 4));
+            v0 = n0; v1 = n1; v2 = n2;
+          }
+        }
+        bp[(size_t)(s0 + u) * P + p] = b;
+      }
+    }
+    __syncthreads();
   }
-  int8_t *out = path + (size_t)p * M;
-  int cur = started ? vwhich3(v0, v1, v2) : -1;
-  for (int s = M - 1; s >= 0; s--) {
-    if (__builtin_signbit(rec[rec_off(s, p, kRecPlanesFull, RP)])) { out[s] = -1; continue; }
-    out[s] = (int8_t)cur;
-    cur = (bp[(size_t)s * P + p] >> (2 * cur)) & 3;
+  if (ss == 0 && p < P) bp[(size_t)M * P + p] = started ? (uint8_t)vwhich3(v0, v1, v2) : (uint8_t)0xFF;
+}
+
+// The walk back along the pointers, kVitPairs pairs per workgroup and kVitBack SNPs at a time: every thread fetches the
+// pointers of one SNP of the stretch into LDS, one lane per pair walks them, every thread writes one SNP of the
+// stretch of every pair's row (path: P x M, -1 where the SNP is dropped for the pair).
+static constexpr int kVitBack = 256;
+__global__ void __launch_bounds__(kVitBack)
+viterbi_back_kernel(const uint8_t *__restrict__ bp, int M, int P, int8_t *__restrict__ path) {
+  __shared__ unsigned char pt[kVitBack][kVitPairs];
+  __shared__ signed char out[kVitPairs][kVitBack + 4];
+  const int p0 = blockIdx.x * kVitPairs, np = min(kVitPairs, P - p0);
+  int cur = 0;
+  if ((int)threadIdx.x < np) {
+    uint8_t e = bp[(size_t)M * P + p0 + threadIdx.x];
+    cur = e == 0xFF ? -1 : (int)e;
+  }
+  for (int hi = M; hi > 0; hi -= kVitBack) {
+    const int lo = max(0, hi - kVitBack), n = hi - lo;
+    if ((int)threadIdx.x < n) {
+      const uint8_t *q = bp + (size_t)(lo + threadIdx.x) * P + p0;
+      for (int j = 0; j < np; j++) pt[threadIdx.x][j] = q[j];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < np) {
+      const int j = threadIdx.x;
+      for (int u = n - 1; u >= 0; u--) {
+        const unsigned b = pt[u][j];
+        if (b == 0xFF) { out[j][u] = -1; continue; }
+        out[j][u] = (signed char)cur;
+        cur = (b >> (2 * cur)) & 3;
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < n)
+      for (int j = 0; j < np; j++) path[(size_t)(p0 + j) * M + lo + threadIdx.x] = out[j][threadIdx.x];
+    __syncthreads();
   }
 }
 

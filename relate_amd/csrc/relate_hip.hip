@@ -1324,10 +1324,13 @@ int decode_block(relate_hip_t h, const int32_t *pairs, int p0, int P, const doub
   if (path) {
     int rc = stage_block(h, pairs, P, true);  // the Viterbi works on log S of every state: full format, own buffer
     if (rc) return rc;
-    HIPCHK(h, h->dBp.ensure((size_t)M * P));
+    HIPCHK(h, h->dBp.ensure((size_t)(M + 1) * P));
     HIPCHK(h, h->dPath.ensure((size_t)M * P));
-    hipLaunchKernelGGL(viterbi_kernel, dim3(blocks_for(P, 256)), dim3(256), 0, h->stream, h->dRecV.p, M, P, h->recPitchV,
-                       h->dParams.p, h->o.double_recom, h->dBp.p, h->dPath.p);
+    hipLaunchKernelGGL(viterbi_fwd_kernel, dim3(blocks_for(P, kVitPairs)), dim3(256), 0, h->stream, h->dRecV.p, M, P,
+                       h->recPitchV, h->dParams.p, h->o.double_recom, h->dBp.p);
+    HIPCHK(h, hipGetLastError());
+    hipLaunchKernelGGL(viterbi_back_kernel, dim3(blocks_for(P, kVitPairs)), dim3(kVitBack), 0, h->stream, h->dBp.p, M, P,
+                       h->dPath.p);
     HIPCHK(h, hipGetLastError());
     rc = copy_to_host(h, path, h->dPath.p, (size_t)M * P);
     if (rc) return rc;
