@@ -243,96 +243,171 @@ __device__ inline int geno_at(const uint64_t *__restrict__ G, int W, int s, int 
 }
 
 // K4: front half of sgl (which_arent_NA, diff, errorNoLD/emission2_new, remove_cross, getHighestId, LD2_new;
-// src/relateHMM.cpp:3424-3472) for a block of P pairs.  One thread per (pair, chunk of `chunk` SNPs); the
-// lanes of a wave are consecutive pairs.  Fast path (no missing genotype among the previous `back` SNPs): the
-// pair's re-indexed LD table equals the global one, so the emission is a lookup in tabL.  Slow path: re-index
-// per the clean form of remove_cross (row r = r-th previous kept SNP, zero beyond depth back2), pick the row
-// with getHighestId's rule and evaluate the conditional emission directly.
+// src/relateHMM.cpp:3424-3472) for a block of P pairs, any back2.  Workgroup = one wave = 64 consecutive pairs x one
+// run of 64 SNPs.  Fast path (no missing genotype among the previous `back` SNPs): the pair's re-indexed LD table equals
+// the global one, so the emission is a lookup in tabL.  Slow path: re-index per the clean form of remove_cross (row r =
+// r-th previous kept SNP, zero beyond depth back2), pick the row with getHighestId's rule and evaluate the conditional
+// emission directly -- a scan of up to back2 depths and the 81-term polynomial.  After one missing genotype the next
+// `back` SNPs of the pair are slow: with back = 50, 10 % of all (pair, SNP) items, so a wave that took them where they
+// fall ran the slow path at practically every step for a few of its lanes.  Instead every lane first walks its run and
+// does the fast items, leaving a bit per slow one; the wave's slow items are then numbered (prefix sum over the lanes)
+// and taken 64 at a time, whichever lane they came from; their S0 factors go through LDS back to the owning lane, which
+// folds them into its product in SNP order.
+static constexpr int kStageRun = 64;
+struct SlowItem {
+  int state;
+  double t, e0, e1, e2;
+};
 template <bool FULL>
-__global__ void stage_pairs_kernel(const uint64_t *__restrict__ G, int M, int W, const int32_t *__restrict__ pairs,
-                                   int P, int chunk, const double *__restrict__ pos, const double *__restrict__ tab1,
-                                   const double *__restrict__ tabL, const int *__restrict__ chooseG,
-                                   const double *__restrict__ mea, const double *__restrict__ pBA,
-                                   const double *__restrict__ pbA, const double *__restrict__ pBa,
-                                   const double *__restrict__ pba, int useLD, int back, int back2, double eps,
-                                   double *__restrict__ rec, int RP, int col0, double *__restrict__ sc_m,
-                                   int *__restrict__ sc_e, int *__restrict__ sc_n) {
-  // pair p of the list goes to column col0 + p of the block
-  long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  int nchunk = (M + chunk - 1) / chunk;
-  if (tid >= (long)P * nchunk) return;
-  int p = (int)(tid % P), c = (int)(tid / P);
-  int i1 = pairs[2 * p], i2 = pairs[2 * p + 1];
-  int s0 = c * chunk, s1 = min(M, s0 + chunk);
-  // state at the chunk start: index of the last kept SNP before s0 (-1: none) and the number of
-  // consecutive kept SNPs immediately before s0 (saturated at back)
-  int last = -1;
-  for (int s = s0 - 1; s >= 0; s--)
-    if (geno_at(G, W, s, i1) && geno_at(G, W, s, i2)) { last = s; break; }
-  int run = 0;
-  for (int s = s0 - 1; s >= 0 && run < back; s--) {
-    if (geno_at(G, W, s, i1) && geno_at(G, W, s, i2)) run++;
-    else break;
+__device__ inline SlowItem stage_slow_item(const uint64_t *__restrict__ G, int M, int W, int i1, int i2, int s,
+                                           const double *__restrict__ pos, const double *__restrict__ mea,
+                                           const double *__restrict__ pBA, const double *__restrict__ pbA,
+                                           const double *__restrict__ pBa, const double *__restrict__ pba, int back,
+                                           int back2, double eps) {
+  SlowItem R{2, 0.0, 1.0, 1.0, 1.0};
+  const int g1 = geno_at(G, W, s, i1), g2 = geno_at(G, W, s, i2);
+  // rows r = 0..back-1 <-> r-th previous kept SNP at distance dd = s-1-s_prev (< back2)
+  int bestS = -1, nfound = 0;  // bestS: SNP of the first row with the strictly largest measure
+  double bv = 0;
+  for (int dd = 0; dd < back2 && nfound < back; dd++) {
+    int sp = s - 1 - dd;
+    if (sp < 0) break;
+    if (geno_at(G, W, sp, i1) == 0 || geno_at(G, W, sp, i2) == 0) continue;
+    double v = mea[(size_t)dd * (M - 1) + (s - 1)];
+    if (nfound == 0 || v > bv) { bv = v; bestS = sp; }
+    nfound++;
   }
+  if (nfound == 0) { bv = 0; bestS = -1; }
+  if (nfound < back && 0.0 > bv) bestS = -1;  // a zero-filled row beyond the window wins (getHighestId, :492)
+  if (bestS < 0) {
+    R.state = 3;  // hap frequencies of that row are zero -> S2 = 0
+  } else {
+    int dd = s - 1 - bestS;
+    size_t at = (size_t)dd * M + s;
+    double S[3], E[3];
+    emis_cond(pBA[at], pbA[at], pBa[at], pba[at], g1, g2, geno_at(G, W, bestS, i1), geno_at(G, W, bestS, i2), eps, S);
+    store_entry(E, S);
+    R.e0 = E[0]; R.e1 = E[1]; R.e2 = E[2];
+  }
+  if (FULL) {  // the pair's own distance: to the last kept SNP before s (a slow item always has one)
+    for (int sp = s - 1; sp >= 0; sp--)
+      if (geno_at(G, W, sp, i1) && geno_at(G, W, sp, i2)) {
+        double d = pos[s] - pos[sp];
+        R.t = d < 0 ? 10000000.0 : d;
+        break;
+      }
+  }
+  return R;
+}
+
+template <bool FULL>
+__global__ void __launch_bounds__(64)
+stage_pairs_kernel(const uint64_t *__restrict__ G, int M, int W, const int32_t *__restrict__ pairs, int P,
+                   const double *__restrict__ pos, const double *__restrict__ tab1, const double *__restrict__ tabL,
+                   const int *__restrict__ chooseG, const double *__restrict__ mea, const double *__restrict__ pBA,
+                   const double *__restrict__ pbA, const double *__restrict__ pBa, const double *__restrict__ pba,
+                   int useLD, int back, int back2, double eps, double *__restrict__ rec, int RP, int col0,
+                   double *__restrict__ sc_m, int *__restrict__ sc_e, int *__restrict__ sc_n) {
+  // pair p of the list goes to column col0 + p of the block
+  __shared__ double slow_s0[64 * kStageRun];
+  __shared__ unsigned long long masks[64];
+  __shared__ int offs[65], ind[64][2];
+  const int groups = (P + 63) / 64;
+  const int c = blockIdx.x / groups, lane = threadIdx.x;
+  const int p = (blockIdx.x % groups) * 64 + lane;
+  const bool live = p < P;
+  const int pc = live ? p : P - 1;
+  const int i1 = pairs[2 * pc], i2 = pairs[2 * pc + 1];
+  const int s0 = c * kStageRun, s1 = min(M, s0 + kStageRun);
   ScaleAcc acc;
   int nkept = 0;
-  for (int s = s0; s < s1; s++) {
-    int g1 = geno_at(G, W, s, i1), g2 = geno_at(G, W, s, i2);
-    int state = 0;
-    double t = 0, e0 = 1, e1 = 1, e2 = 1;
-    if (g1 == 0 || g2 == 0) {
-      run = 0;  // identity step; sign bit of t = dropped
-    } else {
-      state = 2;
-      if (FULL && last >= 0) {  // else first kept SNP: t[0] = 0 in diff (:391-404); unconditional emission (LD2_new :2955-2957)
-        double d = pos[s] - pos[last];
-        t = d < 0 ? 10000000.0 : d;
-      }
-      if (!useLD || last < 0) {
-        const double *e = tab1 + ((size_t)s * 9 + (g1 - 1) * 3 + (g2 - 1)) * 3;
-        e0 = e[0]; e1 = e[1]; e2 = e[2];
-      } else if (run >= min(back, s)) {
-        int sc = s - 1 - chooseG[s];
-        int h1 = geno_at(G, W, sc, i1), h2 = geno_at(G, W, sc, i2);
-        int code = (((g1 - 1) * 3 + (g2 - 1)) * 3 + (h1 - 1)) * 3 + (h2 - 1);
-        const double *e = tabL + ((size_t)s * 81 + code) * 3;
-        e0 = e[0]; e1 = e[1]; e2 = e[2];
-      } else {
-        // slow path: rows r = 0..back-1 <-> r-th previous kept SNP at distance dd = s-1-s_prev (< back2)
-        int bestS = -1, nfound = 0;  // bestS: SNP of the first row with the strictly largest measure
-        double bv = 0;
-        for (int dd = 0; dd < back2 && nfound < back; dd++) {
-          int sp = s - 1 - dd;
-          if (sp < 0) break;
-          if (geno_at(G, W, sp, i1) == 0 || geno_at(G, W, sp, i2) == 0) continue;
-          double v = mea[(size_t)dd * (M - 1) + (s - 1)];
-          if (nfound == 0 || v > bv) { bv = v; bestS = sp; }
-          nfound++;
-        }
-        if (nfound == 0) { bv = 0; bestS = -1; }
-        if (nfound < back && 0.0 > bv) bestS = -1;  // a zero-filled row beyond the window wins (getHighestId, :492)
-        if (bestS < 0) {
-          state = 3;  // hap frequencies of that row are zero -> S2 = 0
-        } else {
-          int dd = s - 1 - bestS;
-          size_t at = (size_t)dd * M + s;
-          double S[3], E[3];
-          emis_cond(pBA[at], pbA[at], pBa[at], pba[at], g1, g2, geno_at(G, W, bestS, i1), geno_at(G, W, bestS, i2),
-                    eps, S);
-          store_entry(E, S);
-          e0 = E[0]; e1 = E[1]; e2 = E[2];
-        }
-      }
-      last = s;
-      if (run < back) run++;
+  unsigned long long slow = 0;
+  if (live) {
+    // state at the run's start: index of the last kept SNP before s0 (-1: none) and the number of consecutive kept SNPs
+    // immediately before s0 (saturated at back)
+    int last = -1;
+    for (int s = s0 - 1; s >= 0; s--)
+      if (geno_at(G, W, s, i1) && geno_at(G, W, s, i2)) { last = s; break; }
+    int run = 0;
+    for (int s = s0 - 1; s >= 0 && run < back; s--) {
+      if (geno_at(G, W, s, i1) && geno_at(G, W, s, i2)) run++;
+      else break;
     }
-    put_record<FULL>(rec, RP, s, col0 + p, state, t, e0, e1, e2, acc, nkept);
-    if ((s & 7) == 7) acc.fold();
+    for (int s = s0; s < s1; s++) {
+      int g1 = geno_at(G, W, s, i1), g2 = geno_at(G, W, s, i2);
+      int state = 0;
+      double t = 0, e0 = 1, e1 = 1, e2 = 1;
+      if (g1 == 0 || g2 == 0) {
+        run = 0;
+      } else {
+        state = 2;
+        if (FULL && last >= 0) {  // else first kept SNP: t[0] = 0 in diff (:391-404); unconditional emission (LD2_new :2955-2957)
+          double d = pos[s] - pos[last];
+          t = d < 0 ? 10000000.0 : d;
+        }
+        if (!useLD || last < 0) {
+          const double *e = tab1 + ((size_t)s * 9 + (g1 - 1) * 3 + (g2 - 1)) * 3;
+          e0 = e[0]; e1 = e[1]; e2 = e[2];
+        } else if (run >= min(back, s)) {
+          int sc = s - 1 - chooseG[s];
+          int h1 = geno_at(G, W, sc, i1), h2 = geno_at(G, W, sc, i2);
+          int code = (((g1 - 1) * 3 + (g2 - 1)) * 3 + (h1 - 1)) * 3 + (h2 - 1);
+          const double *e = tabL + ((size_t)s * 81 + code) * 3;
+          e0 = e[0]; e1 = e[1]; e2 = e[2];
+        } else {
+          state = -1;  // slow: later, with the wave's other slow items
+          slow |= 1ull << (s - s0);
+        }
+        last = s;
+        if (run < back) run++;
+      }
+      if (state >= 0) {
+        put_record<FULL>(rec, RP, s, col0 + p, state, t, e0, e1, e2, acc, nkept);
+        if ((s & 7) == 7) acc.fold();
+      } else {
+        nkept++;
+      }
+    }
+    acc.fold();
   }
-  acc.fold();
-  sc_m[(size_t)c * RP + col0 + p] = acc.m;
-  sc_e[(size_t)c * RP + col0 + p] = acc.e;
-  sc_n[(size_t)c * RP + col0 + p] = nkept;
+  masks[lane] = slow;
+  ind[lane][0] = i1; ind[lane][1] = i2;
+  __syncthreads();
+  if (lane == 0) {
+    int tot = 0;
+    for (int l = 0; l < 64; l++) { offs[l] = tot; tot += __popcll(masks[l]); }
+    offs[64] = tot;
+  }
+  __syncthreads();
+  const int total = offs[64];
+  for (int j = lane; j < total; j += 64) {
+    int lo = 0, hi = 64;  // the lane L with offs[L] <= j < offs[L + 1]
+    while (hi - lo > 1) {
+      int mid = (lo + hi) >> 1;
+      if (offs[mid] <= j) lo = mid; else hi = mid;
+    }
+    const int L = lo;
+    unsigned long long m = masks[L];
+    for (int k = j - offs[L]; k > 0; k--) m &= m - 1;
+    const int s = s0 + (int)__ffsll((long long)m) - 1;
+    const SlowItem R = stage_slow_item<FULL>(G, M, W, ind[L][0], ind[L][1], s, pos, mea, pBA, pbA, pBa, pba, back, back2, eps);
+    ScaleAcc dummy;
+    int nk = 0;
+    put_record<FULL>(rec, RP, s, col0 + (blockIdx.x % groups) * 64 + L, R.state, R.t, R.e0, R.e1, R.e2, dummy, nk);
+    slow_s0[j] = R.state == 3 ? 0.0 : R.e0;
+  }
+  __syncthreads();
+  if (live) {
+    const int n = __popcll(slow), at = offs[lane];
+    for (int k = 0; k < n; k++) {
+      acc.m *= slow_s0[at + k];
+      if ((k & 7) == 7) acc.fold();
+    }
+    acc.fold();
+    sc_m[(size_t)c * RP + col0 + p] = acc.m;
+    sc_e[(size_t)c * RP + col0 + p] = acc.e;
+    sc_n[(size_t)c * RP + col0 + p] = nkept;
+  }
 }
 
 // Folds the per-run partial products of the staging kernels in a fixed order: per pair the factor taken out of its

@@ -378,10 +378,11 @@ int stage_cols(relate_hip_t h, const int32_t *pairs, int n, int col0, int RP, bo
     else STAGE_WIN(false);
 #undef STAGE_WIN
   } else {
-    long nthreads = (long)n * nruns;
+    static_assert(kStageRun == 64, "one bit per SNP of a run");
+    const unsigned ggrid = (unsigned)((size_t)nruns * ((n + 63) / 64));
 #define STAGE_GEN(FULL)                                                                                               \
-  hipLaunchKernelGGL(stage_pairs_kernel<FULL>, dim3(blocks_for(nthreads, 256)), dim3(256), 0, h->stream, h->dG.p, h->M, \
-                     h->W, h->dPairs.p, n, chunk, h->dPos.p, h->dTab1.p, h->dTabL.p, h->dChoose.p, h->dMea.p,         \
+  hipLaunchKernelGGL(stage_pairs_kernel<FULL>, dim3(ggrid), dim3(64), 0, h->stream, h->dG.p, h->M,                    \
+                     h->W, h->dPairs.p, n, h->dPos.p, h->dTab1.p, h->dTabL.p, h->dChoose.p, h->dMea.p,                \
                      h->dPBA.p, h->dPbA.p, h->dPBa.p, h->dPba.p, h->useLD, h->o.back, h->back2, h->o.epsilon, R.p,    \
                      RP, col0, h->dScM.p, h->dScE.p, h->dScN.p)
     if (full) STAGE_GEN(true);
