@@ -22,6 +22,7 @@ SURVEY.md section 8(e); pair order: fast_all_pairs / joblist_fast_all_pairs (src
 """
 import argparse
 import os
+import sys
 import time
 
 import numpy as np
@@ -49,9 +50,16 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def load_inputs(a):
+def load_inputs(a, raw_bed=False):
+    """(geno N x M, pos, chr) -- or, for a SNP-major .bed when the handle can recode it on the GPU (raw_bed), the
+    file's payload as it lies: ("bed", payload, N, cols, pos, chr); the genotype matrix is then never unpacked on the host."""
     if a.plink:
         front = a.plink[:-4] if a.plink.endswith((".bed", ".bim", ".fam")) else a.plink
+        if raw_bed:
+            with open(front + ".bed", "rb") as fh:
+                head = fh.read(3)
+            if len(head) == 3 and head[2]:
+                return ("bed",) + tuple(rio.read_plink_raw(front))
         return rio.load_plink(front)
     if a.prefix:
         front = a.prefix
@@ -72,13 +80,21 @@ def run(a, handle_factory, dist=None, coll_device=None):
     opt = rio.read_options(a.options)
     opt["seed_mode"] = 0
     opt["seed"] = int(a.seed if a.seed is not None else time.time()) & 0xFFFFFFFF
-    geno, pos, chr_ = load_inputs(a)
-    pairs = rio.keep_list_pairs(a.keep) if a.keep else rio.all_pairs(geno.shape[0])
+    marks = [("start", time.perf_counter())]
+    H = handle_factory()
+    inp = load_inputs(a, raw_bed=hasattr(H, "init_globals_bed"))
+    is_bed = isinstance(inp[0], str)
+    n_ind = inp[2] if is_bed else inp[0].shape[0]
+    pairs = rio.keep_list_pairs(a.keep) if a.keep else rio.all_pairs(n_ind)
+    marks.append(("read inputs", time.perf_counter()))
     from . import api, dist as rdist
     b, e = api.shard(len(pairs), rank, world)
     mine = pairs[b:e]
-    H = handle_factory()
-    M = H.init_globals(geno, pos, chr_, opt)
+    if is_bed:
+        M = H.init_globals_bed(inp[1], inp[2], inp[3], inp[4], inp[5], opt)
+    else:
+        M = H.init_globals(inp[0], inp[1], inp[2], opt)
+    marks.append(("load + pre-calculation", time.perf_counter()))
     k1_only = opt["fixK"] == 1 and opt["fixK_val"] == 0
     block = a.block if a.block > 0 else 65536
     post_block = getattr(a, "post_block", 0) or max(1, min(block, (1 << 30) // (24 * M)))
@@ -125,6 +141,7 @@ def run(a, handle_factory, dist=None, coll_device=None):
         with open(post_path + ".json", "w") as fj:
             json.dump({"rows": nrows, "snps": int(M), "rows_per_pair": 1 if k1_only else 2, "first_pair": int(b),
                        "dtype": "<f4", "missing": -1}, fj)
+    marks.append(("fit, decode, posterior rows", time.perf_counter()))
     local = rdist.fits_to_array(fits)
     full = rdist.gather_rows(local, len(pairs), device=coll_device) if dist is not None else local
     if rank == 0:
@@ -138,6 +155,9 @@ def run(a, handle_factory, dist=None, coll_device=None):
                 fe.write("%d\t%d\t%.17g\t%.17g\t%.17g\t%.17g\t%d\t%d\t%d\t%d\n" % (
                     pairs[n][0], pairs[n][1], r[F["a"]], r[F["k2"]], r[F["k1"]], r[F["negloglik"]],
                     int(r[F["timesRun"]]), int(r[F["timesConverged"]]), int(r[F["nsnp"]]), int(r[F["status"]])))
+    marks.append(("gather, .k / .est", time.perf_counter()))
+    if rank == 0 and os.environ.get("RELATE_TIMINGS"):
+        sys.stderr.write("timings: " + ", ".join("%s %.2f s" % (n, t - marks[i][1]) for i, (n, t) in enumerate(marks[1:])) + "\n")
     return full
 
 

@@ -998,20 +998,26 @@ decode_bwd_kernel(const double *__restrict__ rec, const double *__restrict__ tsh
     b0 = bend[at]; b1 = bend[at + 1]; b2 = bend[at + 2];
   }
   const RecCol col(rec, tsh, own, RP, col0 + pc, M);
-  for (int tb = (se - 1) & ~(kTile - 1); tb >= sb; tb -= kTile) {
-    int te = min(se, tb + kTile);
-    Rec R[kTile];
+  // The records and the checkpoint of the NEXT tile are fetched before this tile is worked on: the kernel holds one
+  // wave per SIMD (362 VGPRs), so nothing else would cover its memory latency while it computes.
+  auto load_tile = [&](int tb, Rec (&R)[kTile], ChunkProd &X) {
 #pragma unroll
     for (int u = 0; u < kTile; u += 2) col.at2(min((tb + u) >> 1, col.hmax), R[u], R[u + 1]);
-    ChunkProd X;
-    {
-      const double *qm = ck.m(tb / kTile, pc);
-      const int *qe = ck.e(tb / kTile, pc);
+    const double *qm = ck.m(tb / kTile, pc);
+    const int *qe = ck.e(tb / kTile, pc);
 #pragma unroll
-      for (int i = 0; i < 9; i++) X.m[i] = qm[i * 64];
+    for (int i = 0; i < 9; i++) X.m[i] = qm[i * 64];
 #pragma unroll
-      for (int i = 0; i < 3; i++) X.e[i] = qe[i * 64];
-    }
+    for (int i = 0; i < 3; i++) X.e[i] = qe[i * 64];
+  };
+  Rec R[kTile];
+  ChunkProd X;
+  load_tile((se - 1) & ~(kTile - 1), R, X);
+  for (int tb = (se - 1) & ~(kTile - 1); tb >= sb; tb -= kTile) {
+    int te = min(se, tb + kTile);
+    Rec Rn[kTile];
+    ChunkProd Xn;
+    load_tile(max(tb - kTile, sb), Rn, Xn);  // (the chunk's first tile once more at the end: never used)
     double f0 = a0, f1 = a1, f2 = a2;
     apply_chunk_fwd(f0, f1, f2, X);
     norm_fast(f0, f1, f2);
@@ -1041,6 +1047,9 @@ decode_bwd_kernel(const double *__restrict__ rec, const double *__restrict__ tsh
       }
     }
     __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kTile; u++) R[u] = Rn[u];
+    X = Xn;
   }
 }
 

@@ -1858,6 +1858,23 @@ int relate_hip_like_noalloc(relate_hip_t h, int P, const double *d_params, int E
   return RELATE_OK;
 }
 
+namespace {
+// Pairs per fitted block: what the records allow, evened out over the blocks of the call (a last block of a fifth of
+// the size pays a whole block's tail of small launches for a fifth of the pairs).  RELATE_FIT_BLOCK_MAX caps it (tuning).
+size_t fit_block_pairs(relate_hip_t h, long P) {
+  size_t lim = pair_block_limit(h, {need_rec(h)});
+  if (const char *e = getenv("RELATE_FIT_BLOCK_MAX")) {
+    long v = atol(e);
+    if (v >= 64 && (size_t)v < lim) lim = (size_t)v;
+  }
+  if (P > 0 && (size_t)P > lim) {
+    const size_t nb = ((size_t)P + lim - 1) / lim;
+    lim = ((size_t)P + nb - 1) / nb;
+  }
+  return lim;
+}
+}  // namespace
+
 int relate_hip_fit(relate_hip_t h, const int32_t *pairs, int P, const double *starts, relate_fit *out,
                    double *conv_out) {
   int rc = require_ready(h);
@@ -1866,7 +1883,7 @@ int relate_hip_fit(relate_hip_t h, const int32_t *pairs, int P, const double *st
   h->timings[1] = 0;
   for (double &v : h->like_stats) v = 0;
   if (conv_out) std::memset(conv_out, 0, sizeof(double) * (size_t)P * std::max(1, h->o.timesToRun) * 4);
-  size_t lim = pair_block_limit(h, {need_rec(h)});
+  size_t lim = fit_block_pairs(h, P);
   for (long b0 = 0; b0 < P; b0 += (long)lim) {
     int pb = (int)std::min<long>((long)lim, P - b0);
     rc = stage_block(h, pairs + 2 * b0, pb);
@@ -1923,7 +1940,7 @@ int relate_hip_run_pairs(relate_hip_t h, const int32_t *pairs, int P, const doub
   // The fit wants as many pairs in flight as the records allow (its launches are single sweeps only with tens of
   // thousands of lanes); the posteriors of a fitted block are then decoded in sub-blocks sized to what is left for
   // the posterior and checkpoint buffers, each a range of columns of the records already staged.
-  size_t lim = pair_block_limit(h, {need_rec(h)});
+  size_t lim = fit_block_pairs(h, P);
   std::vector<double> par;
   for (long b0 = 0; b0 < P; b0 += (long)lim) {
     int pb = (int)std::min<long>((long)lim, P - b0);

@@ -89,9 +89,11 @@ def load_text(geno, pos, chr_=None):
     return sort_snps(g, p, c)
 
 
-def load_plink(prefix):
+def read_bim(path):
+    """Chromosome and position columns of a .bim file (doBimFile, src/filereader_and_conversions.cpp:593-657): six
+    columns per line, reading stops at the first empty line."""
     chrs, poss = [], []
-    with open(prefix + ".bim") as fh:
+    with open(path) as fh:
         for line in fh:
             t = line.split()
             if not t:
@@ -100,6 +102,11 @@ def load_plink(prefix):
                 raise ValueError("plink bim file doesn't have 6 columns")
             chrs.append(int(t[0]))
             poss.append(float(t[3]))
+    return chrs, poss
+
+
+def load_plink(prefix):
+    chrs, poss = read_bim(prefix + ".bim")
     with open(prefix + ".fam") as fh:
         n_ind = sum(1 for line in fh if line.strip())
     raw = np.fromfile(prefix + ".bed", dtype=np.uint8)
@@ -126,16 +133,7 @@ def read_plink_raw(prefix):
     """PLINK input for relate_hip_load_bed: the .bed payload as it lies in the file (SNP-major only) plus the short
     per-SNP vectors after doBimFile's autosome filter and mysort -- the genotype matrix itself is never unpacked on
     the host.  Returns (payload uint8[n_snp * ceil(N/4)], N, cols, pos, chr)."""
-    chrs, poss = [], []
-    with open(prefix + ".bim") as fh:
-        for line in fh:
-            t = line.split()
-            if not t:
-                break
-            if len(t) != 6:
-                raise ValueError("plink bim file doesn't have 6 columns")
-            chrs.append(int(t[0]))
-            poss.append(float(t[3]))
+    chrs, poss = read_bim(prefix + ".bim")
     with open(prefix + ".fam") as fh:
         n_ind = sum(1 for line in fh if line.strip())
     raw = np.fromfile(prefix + ".bed", dtype=np.uint8)

@@ -82,3 +82,27 @@ def test_bed_route_equals_matrix_route(case, tmp_path):
     pairs = [(0, 1), (2, n_ind - 1), (3, 7)]
     par = np.array([[(0.05, 0.1, 0.3), (0.02, 0.0, 0.5)]] * len(pairs))
     assert np.array_equal(A.like(pairs, par), B.like(pairs, par))
+
+
+def test_read_bim_follows_the_reference_reader(tmp_path):
+    """relate_amd.io.read_bim: six columns per line, reading stops at the first empty line (doBimFile), a line with
+    another column count is an error."""
+    import pytest
+    from relate_amd import io as rio
+    lines = ["%d\trs%d\t0\t%d\tA\tG" % (1 + n // 4, n, 1000 * n + 7) for n in range(12)]
+    p = tmp_path / "a.bim"
+    p.write_text("\n".join(lines) + "\n")
+    c, q = rio.read_bim(str(p))
+    assert c == [1 + n // 4 for n in range(12)] and q == [float(1000 * n + 7) for n in range(12)]
+    p.write_text("\n".join(lines))                                   # no newline at the end
+    assert rio.read_bim(str(p)) == (c, q)
+    p.write_text("\n".join(lines[:5]) + "\n\n" + "\n".join(lines[5:]) + "\n")   # stops at the empty line
+    assert rio.read_bim(str(p)) == (c[:5], q[:5])
+    p.write_text("\n".join(lines[:5]) + "\n \t\n" + "\n".join(lines[5:]) + "\n")
+    assert rio.read_bim(str(p)) == (c[:5], q[:5])
+    p.write_text("\n".join(lines[:3]) + "\n1 rs 0 5 A\n")             # five columns
+    with pytest.raises(ValueError):
+        rio.read_bim(str(p))
+    p.write_text("1 rs1 0 5 A G 2 rs2 0\n9 A G\n")                    # twelve tokens on two lines, not 6 + 6
+    with pytest.raises(ValueError):
+        rio.read_bim(str(p))

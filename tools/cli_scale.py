@@ -44,7 +44,7 @@ try:
         size = os.path.getsize(os.path.join(tmp, "out.post")) if os.path.exists(os.path.join(tmp, "out.post")) else 0
         print("relateHMM_hip %s: N=%d M=%d P=%d pairs: %.1f s wall = %.0f pairs/s; .post %.2f GB" % (
             label, N, M, P, dt, P / dt, size / 1e9), flush=True)
-    env = dict(os.environ, PYTHONPATH=ROOT)
+    env = dict(os.environ, PYTHONPATH=ROOT, RELATE_TIMINGS="1")
     legs = (("-no-post", ["-no-post"]), ("-post-format bin", ["-post-format", "bin"]))
     if KEEP:
         legs = (("-d keep -no-post", ["-d", "d.keep", "-no-post"]),)
@@ -56,6 +56,9 @@ try:
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         print("relate_amd.allpairs %s: N=%d M=%d P=%d pairs: %.1f s wall = %.0f pairs/s" % (label, N, M, P, dt, P / dt),
               flush=True)
+        if os.environ.get("RELATE_FIT_TRACE"):
+            print("".join(l + "\n" for l in r.stderr.splitlines() if l.startswith(("fit block", "timings:"))), end="", flush=True)
+            print(r.stdout[-1500:], flush=True)
         est = np.loadtxt(os.path.join(tmp, "ap" + label[1:3] + ".est"))
         print("  .est rows %d, status != 0: %d, k1 > 0.3: %d, mean -logL %.1f" % (
             len(est), int((est[:, -1] != 0).sum()), int((est[:, 4] > 0.3).sum()), est[:, 5].mean()), flush=True)
