@@ -628,3 +628,38 @@ def test_dropped_run_across_a_chromosome_break_with_a_non_negative_distance(orac
             dropped = np.setdiff1d(np.arange(M), idxs[n])
             assert (post[n][:, dropped] == -1).all()
         H.close()
+
+
+def test_restarts_ahead_of_need_change_no_outcome(oracle, monkeypatch):
+    """The fit starts every restart of a pair at once when first waves are seen not to settle pairs (RELATE_FIT_EAGER = 1
+    forces it, 0 forbids it).  Starts are drawn and results consumed in index order and runs beyond the stopping point
+    are dropped unseen, so estimates, -logL, timesRun, timesConverged and convInfo must equal the sequential rule's bit
+    for bit -- in the mode where every pair uses all its restarts (2-parameter calcA) and in the one where most pairs
+    stop after timesToConverge runs (3 parameters).  (SNP-chunked route off: its summation order depends on the lane
+    count of a launch, which the schedule changes.)"""
+    import relate_amd
+    from relate_amd import synth
+    monkeypatch.setenv("RELATE_SINGLE_SWEEP_LANES", "1")
+    N, M = 40, 1200
+    g, pos, chr_, _ = synth.make_dataset(N, M, n_related=6, seed=11)
+    pairs = synth.all_pairs(N)[:500]
+    for name in ("options.all.pair.txt", "options.single.pair.txt"):
+        opt = dict(pc.options(name))
+        opt.update(seed_mode=1, seed=77)
+        if name == "options.single.pair.txt":
+            opt.update(timesToConverge=2, timesToRun=6)   # most pairs stop after two runs: four started ahead are dropped
+        out = {}
+        for eager in ("0", "1"):
+            monkeypatch.setenv("RELATE_FIT_EAGER", eager)
+            H = relate_amd.Relate(0)
+            H.init_globals(g, pos, chr_, opt)
+            res, conv = H.fit(pairs, want_conv=True)
+            keys = sorted(res[0])
+            out[eager] = (np.array([[float(r[k]) for k in keys] for r in res]), conv)
+            H.close()
+        assert np.array_equal(out["0"][0], out["1"][0], equal_nan=True), name
+        assert np.array_equal(out["0"][1], out["1"][1], equal_nan=True), name
+        runs = out["0"][0][:, keys.index("timesRun")]
+        assert runs.min() >= 1
+        if name == "options.single.pair.txt":
+            assert (runs < 6).mean() > 0.5 and runs.min() == 2
