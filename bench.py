@@ -50,12 +50,13 @@ def algorithmic_bytes(like_chunks, decode_chunks):
 SURVEY_BYTES = {"like": 0.5, "decode": 0.5 + 8.0 * 3}
 
 
-# FP64 VALU instructions per lane-step of the likelihood kernels, counted by rocprofv3 (SQ_INSTS_VALU / wave-steps,
-# profiles/r01_pmc_sq.json): single sweep 27.8 (derived), chunk-product sweep (three row vectors) 55.2 at this data set's SNP
-# density (four fifths of the record groups take the shortest series).  Peak = one FP64
-# instruction per lane per 4 cycles per SIMD at the 2.4 GHz boost clock; under this load the part holds 1.6-1.7 GHz
-# (GRBM_GUI_ACTIVE / 8 / kernel time) and a pure FMA stream measures 28.8e12 lane-FMA/s (tools/ubench/fp64_ops.hip).
-VALU_PER_STEP = {1: 28.3, 3: 53.0}
+# Vector instructions per point-step of the likelihood kernels, counted by rocprofv3 (SQ_INSTS_VALU x 64 / point-steps;
+# profiles/r02_pmc_like_sweeps.txt, profiles/r02_pmc_sq.json): sweeps 26.3 (single, two points per lane) to 28.9 (two-sided,
+# one point per lane) -- 27.3, the two-sided two-points-per-lane figure, is used for a fit's mix; chunk-product sweep
+# (three row vectors) 53.5 at this data set's SNP density (four fifths of the record groups take the shortest series).
+# Peak = one FP64 instruction per lane per 4 cycles per SIMD at the 2.4 GHz boost clock; under this load the part holds
+# 1.6-1.7 GHz and a pure FMA stream measures 28.8e12 lane-FMA/s (tools/ubench/fp64_ops.hip).
+VALU_PER_STEP = {1: 27.3, 3: 53.5}
 FP64_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9  # 39.3e12 at the 2.4 GHz boost clock
 
 
@@ -401,7 +402,7 @@ def main():
                          "note": "dominant = the HBM-bound kernel with the largest share of the step (the likelihood kernels, a comparable share, are FP64-VALU-bound: roofline_fp64); traffic = HBM bytes per launch from the "
                                  "committed PMC passes (profiles/pmc_traffic.json), null if they were taken on another "
                                  "configuration.  The likelihood kernels are FP64-VALU-bound by design (two expm1 "
-                                 "per lane-step, 5 lanes share one 32 B record): see roofline_fp64"},
+                                 "per lane-step, 5 lanes share one 16 B record): see roofline_fp64"},
             "roofline_fp64": {"kernel": kernel_name["like"], "valu_insts_per_lane_step": valu,
                               "achieved": like_steps_s * valu / 1e12, "peak": FP64_LANE_OPS_PEAK / 1e12,
                               "unit": "T lane-instructions/s", "frac": like_steps_s * valu / FP64_LANE_OPS_PEAK,
