@@ -2233,8 +2233,10 @@ int linkage_on_device(relate_hip_t h, float *dPp, int R, int M, const float *pos
     hipLaunchKernelGGL(lk_col_means_kernel, dim3(blocks_for(M, 256), nb), dim3(256), 0, st, dPp, M, a, LA, n, LN, missing,
                        dU1.p, dU0.p);
     L2CHK(hipGetLastError());
-    hipLaunchKernelGGL(lk_perm_scalars_kernel, dim3(blocks_for(nb, 64)), dim3(64), 0, st, dK.p, dCov.p, R, a, LA, n, LN, nb,
-                       dScal.p);
+    const size_t list_bytes = sizeof(int) * ((size_t)LA + LN);
+    const int lds = list_bytes <= 48 * 1024 ? 1 : 0;
+    hipLaunchKernelGGL(lk_perm_scalars_kernel, dim3(nb), dim3(64), lds ? list_bytes : 0, st, dK.p, dCov.p, R, a, LA, n, LN,
+                       nb, lds, dScal.p);
     L2CHK(hipGetLastError());
     hipLaunchKernelGGL(lk_statistic_kernel, dim3(blocks_for(M, 256), nb), dim3(256), 0, st, dU1.p, dU0.p, dScal.p, M);
     L2CHK(hipGetLastError());
