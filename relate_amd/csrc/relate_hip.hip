@@ -821,7 +821,11 @@ struct FitPop {
           else draw_start(rng[p], S, o->fixK, st);  // the pair's rand() stream: in index order
           start_to_x(S, st, x0.data());
           a.r = reinterpret_cast<Run *>(arena->take());
-          if (!a.r) return -1;
+          if (!a.r) {  // out of host memory: the slabs taken in this pass hold no run yet
+            for (size_t i = n_before; i < active.size(); i++) arena->give(reinterpret_cast<unsigned char *>(active[i].r));
+            active.resize(n_before);
+            return -1;
+          }
           x0s.push_back(x0);
           active.push_back(a);
         }
