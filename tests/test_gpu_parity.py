@@ -601,33 +601,34 @@ def test_dropped_run_across_a_chromosome_break_with_a_non_negative_distance(orac
     g[0, 1000] = 0
     g[1, 998:1004] = 0
     g[2, 995:1000] = 0
-    opt = dict(pc.options("options.all.pair.txt"))
-    p = pc.oracle_precalc(oracle, g, pos, opt)
-    assert p["keep"].all()
-    pairs = [(0, 3), (1, 3), (0, 1), (2, 3), (3, 4), (1, 2)]
-    pars = np.array([(0.05, 0.2, 0.3), (0.1, 0.0, 0.4), (0.02, 0.3, 0.5), (0.08, 0.1, 0.6)])
-    want_like, want_post, idxs = [], [], []
-    for (i, j) in pairs:
-        st = pc.oracle_stage(oracle, p, opt, i, j)
-        idxs.append(np.where(st["keep"] == 1)[0])
-        want_like.append([oracle.like(d, *st["Sk"], st["t"], 0, opt["alim1"]) for d in pars])
-        want_post.append(oracle.decode(pars[0], *st["Sk"], st["t"], 0))
-    # the distances the reference uses across the break for the marked pairs: +0.51 / +0.56, not 1e7
-    st = pc.oracle_stage(oracle, p, opt, 0, 3)
-    assert abs(st["t"][1000] - (pos[1001] - pos[999])) < 1e-12
-    for lanes in ("1", "1000000"):           # single / two-sided sweeps; cut along the SNP axis
-        monkeypatch.setenv("RELATE_SINGLE_SWEEP_LANES", lanes)
-        H = relate_amd.Relate(0)
-        H.init_globals(g, pos, chr_, opt)
-        got = H.like(pairs, np.broadcast_to(pars, (len(pairs),) + pars.shape).copy())
-        np.testing.assert_allclose(got, want_like, rtol=1e-10)
-        post, _, ns = H.decode(pairs, np.broadcast_to(pars[0], (len(pairs), 3)).copy())
-        for n in range(len(pairs)):
-            assert ns[n] == len(idxs[n])
-            np.testing.assert_allclose(post[n][:, idxs[n]], want_post[n], atol=1e-8)
-            dropped = np.setdiff1d(np.arange(M), idxs[n])
-            assert (post[n][:, dropped] == -1).all()
-        H.close()
+    for dr in (0, 1):                         # both transition models (double recombination: T = e I + (1 - e) 1 k')
+        opt = dict(pc.options("options.all.pair.txt"), double_recom=dr)
+        p = pc.oracle_precalc(oracle, g, pos, opt)
+        assert p["keep"].all()
+        pairs = [(0, 3), (1, 3), (0, 1), (2, 3), (3, 4), (1, 2)]
+        pars = np.array([(0.05, 0.2, 0.3), (0.1, 0.0, 0.4), (0.02, 0.3, 0.5), (0.08, 0.1, 0.6)])
+        want_like, want_post, idxs = [], [], []
+        for (i, j) in pairs:
+            st = pc.oracle_stage(oracle, p, opt, i, j)
+            idxs.append(np.where(st["keep"] == 1)[0])
+            want_like.append([oracle.like(d, *st["Sk"], st["t"], dr, opt["alim1"]) for d in pars])
+            want_post.append(oracle.decode(pars[0], *st["Sk"], st["t"], dr))
+        # the distances the reference uses across the break for the marked pairs: +0.51 / +0.56, not 1e7
+        st = pc.oracle_stage(oracle, p, opt, 0, 3)
+        assert abs(st["t"][1000] - (pos[1001] - pos[999])) < 1e-12
+        for lanes in ("1", "1000000"):           # single / two-sided sweeps; cut along the SNP axis
+            monkeypatch.setenv("RELATE_SINGLE_SWEEP_LANES", lanes)
+            H = relate_amd.Relate(0)
+            H.init_globals(g, pos, chr_, opt)
+            got = H.like(pairs, np.broadcast_to(pars, (len(pairs),) + pars.shape).copy())
+            np.testing.assert_allclose(got, want_like, rtol=1e-10)
+            post, _, ns = H.decode(pairs, np.broadcast_to(pars[0], (len(pairs), 3)).copy())
+            for n in range(len(pairs)):
+                assert ns[n] == len(idxs[n])
+                np.testing.assert_allclose(post[n][:, idxs[n]], want_post[n], atol=1e-8)
+                dropped = np.setdiff1d(np.arange(M), idxs[n])
+                assert (post[n][:, dropped] == -1).all()
+            H.close()
 
 
 def test_restarts_ahead_of_need_change_no_outcome(oracle, monkeypatch):
