@@ -664,3 +664,4 @@ def test_restarts_ahead_of_need_change_no_outcome(oracle, monkeypatch):
         assert runs.min() >= 1
         if name == "options.single.pair.txt":
             assert (runs < 6).mean() > 0.5 and runs.min() == 2
+
