@@ -35,7 +35,7 @@
 // chunked step costs ~2x a plain one.  A workgroup is 256 lanes of ONE chunk, so loop bounds are scalar.
 // Between the two, a launch of up to one wave per SIMD runs two-sided (like_halves_kernel): forward half . backward half.
 //
-// Memory.  Every lane streams its column of records, 4 records (96 B) per group, double-buffered in registers; the row
+// Memory.  Every lane streams its column of records, 4 records (64 B) per group, double-buffered in registers; the row
 // base is wave-uniform (scalar), the lane adds its 32-bit column offset.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -374,7 +374,7 @@ __device__ __forceinline__ void fwd_group(const LaneC &C, const Rec (&R)[kGroup]
 
 // Streams the records of rows [sb, se) of one column through two callbacks: groups of kGroup records (the bulk) and
 // single records (a tail of < NBUF * kGroup rows).  NBUF groups are in flight per lane in a statically indexed register
-// ring, so a wave always has (NBUF - 1) * 96 B per lane on the way from HBM while it computes: with 2-3 waves per SIMD
+// ring, so a wave always has (NBUF - 1) * 64 B per lane on the way from HBM while it computes: with 2-3 waves per SIMD
 // that covers the ~2 us loaded HBM latency.
 template <int NBUF, class FG, class FT>
 __device__ __forceinline__ void stream_records(const RecCol &col, int sb, int se, int M, FG &&on_group, FT &&on_tail) {
@@ -399,7 +399,7 @@ __device__ __forceinline__ void stream_records(const RecCol &col, int sb, int se
   for (; s < se; s++) on_tail(col.at(s), s);
 }
 
-// groups in flight per lane, per kernel (register budget: 24 VGPRs per group)
+// groups in flight per lane, per kernel (register budget: 16 VGPRs per group)
 static constexpr int kNbufChunk = 2;
 
 // forward recursion over rows [sb, se) for NV vectors
