@@ -684,10 +684,12 @@ stage_pairs_win_kernel(const uint64_t *__restrict__ Gt, int M, int Wt, const int
 // of (L, F] are marked.  Several breaks inside one run find the same L and F and write the same values.
 __global__ void boundary_fixup_kernel(const uint64_t *__restrict__ G, int M, int W, const int32_t *__restrict__ pairs,
                                       int P, const int *__restrict__ bnd, int nb, const double *__restrict__ pos,
-                                      double *__restrict__ rec, int RP, int col0, int *__restrict__ own) {
+                                      double *__restrict__ rec, int RP, int col0, int *__restrict__ own,
+                                      const int *__restrict__ nsnp) {
   long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= (long)P * nb) return;
   const int p = (int)(tid % P), b = bnd[tid / P];
+  if (nsnp[col0 + p] == 0) return;  // no kept SNP: nothing to mark (and nothing to stop the scans below)
   const int i1 = pairs[2 * p], i2 = pairs[2 * p + 1];
   int L = -1, F = -1;
   for (int s = b - 1; s >= 0; s--)

@@ -391,18 +391,17 @@ int stage_cols(relate_hip_t h, const int32_t *pairs, int n, int col0, int RP, bo
   }
   HIPCHK(h, hipGetLastError());
   if (!full) {
-    HIPCHK(h, hipMemsetAsync(h->dPairOwn.p + col0, 0, sizeof(int) * n, h->stream));
-    if (h->nBnd > 0) {  // runs of dropped SNPs across a chromosome break (kernels_emis.hpp)
-      hipLaunchKernelGGL(boundary_fixup_kernel, dim3(blocks_for((long)n * h->nBnd, 256)), dim3(256), 0, h->stream,
-                         h->dG.p, h->M, h->W, h->dPairs.p, n, h->dBnd.p, h->nBnd, h->dPos.p, R.p, RP, col0,
-                         h->dPairOwn.p);
-      HIPCHK(h, hipGetLastError());
-    }
-  }
-  if (!full) {
     hipLaunchKernelGGL(scale_reduce_kernel, dim3(blocks_for(n, 64)), dim3(64 * kScaleSeg), 0, h->stream, h->dScM.p,
                        h->dScE.p, h->dScN.p, nruns, RP, col0, n, h->dPairM.p, h->dPairE.p, h->dNsnp.p);
     HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemsetAsync(h->dPairOwn.p + col0, 0, sizeof(int) * n, h->stream));
+    if (h->nBnd > 0) {  // runs of dropped SNPs across a chromosome break (kernels_emis.hpp); after the counts: a pair
+                        // without a kept SNP would have every thread of it scan the whole row for one
+      hipLaunchKernelGGL(boundary_fixup_kernel, dim3(blocks_for((long)n * h->nBnd, 256)), dim3(256), 0, h->stream,
+                         h->dG.p, h->M, h->W, h->dPairs.p, n, h->dBnd.p, h->nBnd, h->dPos.p, R.p, RP, col0,
+                         h->dPairOwn.p, h->dNsnp.p);
+      HIPCHK(h, hipGetLastError());
+    }
   }
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
   if (!full)
