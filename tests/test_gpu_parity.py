@@ -665,3 +665,74 @@ def test_restarts_ahead_of_need_change_no_outcome(oracle, monkeypatch):
         if name == "options.single.pair.txt":
             assert (runs < 6).mean() > 0.5 and runs.min() == 2
 
+
+
+def test_random_small_data_sets_with_heavy_missingness_and_odd_chromosome_breaks(oracle):
+    """Ten small random data sets against the oracle: 10-40 % missing genotypes in runs of random length, three to six
+    'chromosomes' whose positions restart at random offsets -- so that runs of dropped SNPs cross breaks with negative
+    and with non-negative distances, lead a chromosome, lead the data set or end it -- back = 2..5 and both transition
+    models.  Likelihoods at three points (1e-10 relative) and posteriors (1e-8) of all 28 pairs of 8 individuals (those
+    with finite emissions), the kept-SNP counts and the -1 pattern of the dropped SNPs."""
+    import relate_amd
+    pars = np.array([(0.05, 0.2, 0.3), (0.1, 0.0, 0.4), (0.02, 0.3, 0.5)])
+    checked = marked = 0
+    for seed in range(10):
+        rng = np.random.default_rng(1000 + seed)
+        N, M = 8, int(rng.integers(90, 220))
+        nchr = int(rng.integers(3, 7))
+        cuts = np.sort(rng.choice(np.arange(5, M - 5), size=nchr - 1, replace=False))
+        chr_ = np.zeros(M, dtype=np.int32)
+        pos = np.zeros(M)
+        start = 0
+        for c, end in enumerate(list(cuts) + [M]):
+            n = end - start
+            base = rng.choice([0.0, 0.5, float(rng.uniform(0, 30))])     # some chromosomes start beyond the last one's end
+            pos[start:end] = base + np.cumsum(rng.uniform(0.02, 0.6, size=n))
+            chr_[start:end] = c + 1
+            start = end
+        g = rng.integers(1, 4, size=(N, M)).astype(np.uint8)
+        g[6, :] = 1
+        g[7, :] = 3                                                       # every SNP passes the MAF filter
+        for i in range(6):
+            s = 0
+            while s < M:
+                run = int(rng.integers(1, 9))
+                if rng.random() < rng.choice([0.1, 0.25, 0.4]):
+                    g[i, s:s + run] = 0
+                s += run
+        if seed % 3 == 0:
+            g[0, :int(rng.integers(1, 6))] = 0                            # leading missing SNPs
+            g[1, M - int(rng.integers(1, 6)):] = 0                        # trailing
+            for c in cuts[:2]:
+                g[2, c:c + int(rng.integers(1, 4))] = 0                   # the first SNPs of a chromosome
+                g[3, c - int(rng.integers(1, 4)):c] = 0                   # the last SNPs of the one before
+        dr = seed % 2
+        opt = dict(pc.options("options.all.pair.txt"), double_recom=dr, back=int(rng.integers(2, 6)))
+        opt["back2"] = 2 * opt["back"]
+        if seed % 4 != 0:
+            opt["ld_adj"] = 0    # random genotypes of 8 individuals leave most LD-conditional emissions at zero: most
+                                 # data sets run without the LD adjustment, so that every pair has a finite likelihood
+        p = pc.oracle_precalc(oracle, g, pos, opt)
+        assert p["keep"].all()
+        H = relate_amd.Relate(0)
+        H.init_globals(g, pos, chr_, opt)
+        pairs = [(i, j) for i in range(N) for j in range(i + 1, N)]
+        got = H.like(pairs, np.broadcast_to(pars, (len(pairs),) + pars.shape).copy())
+        post, _, ns = H.decode(pairs, np.broadcast_to(pars[0], (len(pairs), 3)).copy())
+        for n, (i, j) in enumerate(pairs):
+            st = pc.oracle_stage(oracle, p, opt, i, j)
+            idx = np.where(st["keep"] == 1)[0]
+            assert ns[n] == st["m"] == len(idx)
+            if st["m"] < 2 or not (np.isfinite(st["S"]).all() and (st["S"] > 0).all()):
+                continue
+            # does this pair hold a run of dropped SNPs across a break whose kept ends lie a non-negative distance apart?
+            gap = np.diff(idx) > 1
+            crosses = chr_[idx[1:]] != chr_[idx[:-1]]
+            marked += int((gap & crosses & (np.diff(pos[idx]) >= 0)).any())
+            want = [oracle.like(d, *st["Sk"], st["t"], dr, opt["alim1"]) for d in pars]
+            np.testing.assert_allclose(got[n], want, rtol=1e-10, err_msg="seed %d pair %d %d" % (seed, i, j))
+            np.testing.assert_allclose(post[n][:, idx], oracle.decode(pars[0], *st["Sk"], st["t"], dr), atol=1e-8)
+            assert (post[n][:, np.setdiff1d(np.arange(M), idx)] == -1).all()
+            checked += 1
+        H.close()
+    assert checked > 150 and marked > 10      # the case that does not compose was really among them

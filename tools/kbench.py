@@ -18,6 +18,7 @@ ap.add_argument("--snps", type=int, default=100000)
 ap.add_argument("--inds", type=int, default=400)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--decode", action="store_true")
+ap.add_argument("--miss", type=float, default=0.001, help="missing-genotype rate of the synthetic data")
 ap.add_argument("--lib", default=None, help="experiment: load this build of the library instead")
 ap.add_argument("shapes", nargs="+")
 a = ap.parse_args()
@@ -26,7 +27,7 @@ if a.lib:
     relate_amd.api.LIB_PATH = os.path.abspath(a.lib)
 opt = bench.opts_all_pair()
 opt["back2"] = 2 * opt["back"]
-geno, pos, chr_, _ = synth.make_dataset(a.inds, a.snps, device="cuda:0")
+geno, pos, chr_, _ = synth.make_dataset(a.inds, a.snps, device="cuda:0", miss=a.miss)
 H = relate_amd.Relate(0)
 M = H.init_globals(geno, pos, chr_, opt)
 allp = synth.all_pairs(a.inds)
