@@ -387,6 +387,8 @@ def main():
             "unit": "pair*SNP HMM steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "value_note": "kernel-resident: posteriors stay in HBM.  With the 24 B of posterior rows per pair and SNP copied "
+                          "to the host the same step runs at 1.1-1.5e10 steps/s (PCIe; tools/pcie_rate.py, DESIGN.md section 6)",
             "config": {"workload": "config 4 synthetic all-pairs, pair block per step: %d individuals x %d SNPs "
                                    "(%d after MAF filter), %d pairs/GPU/step, E=%d like points + decode, "
                                    "options.all.pair.txt semantics (calcA, back=5)" % (args.inds, args.snps, M, P, E),
