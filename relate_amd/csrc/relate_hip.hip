@@ -282,14 +282,17 @@ class HostPool {
   long gen_ = 0;
   int pending_ = 0;
 };
+HostPool &host_pool() {  // one pool for the process (not one per call site of the template below)
+  static HostPool *pool = new HostPool(host_threads());
+  return *pool;
+}
 template <class F>
 void parallel_for(size_t n, F &&fn, size_t serial_below = 4096) {  // fn(begin, end)
   int nt = host_threads();
   if (n < serial_below || nt == 1) { fn((size_t)0, n); return; }
-  static HostPool *pool = new HostPool(nt);
   {
     const std::function<void(size_t, size_t)> job = [&fn](size_t lo, size_t hi) { fn(lo, hi); };
-    if (pool->try_run(n, job)) return;
+    if (host_pool().try_run(n, job)) return;
   }
   std::vector<std::thread> th;
   size_t per = (n + nt - 1) / nt;
