@@ -220,7 +220,7 @@ int fail(relate_hip_t h, int code, const std::string &msg) {
 inline unsigned blocks_for(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 // Host-side control work of the batched optimiser (one L-BFGS-B step and the objective wrappers of every active run
-// per round) spread over a few threads: runs are independent objects.  RELATE_HOST_THREADS overrides (default: up to 8).
+// per round) spread over a few threads: runs are independent objects.  RELATE_HOST_THREADS overrides (default: up to 8, or OMP_NUM_THREADS if that is larger).
 int host_threads() {
   static int n = [] {
     int v = 0;
@@ -228,6 +228,12 @@ int host_threads() {
     if (v < 1) {
       v = (int)std::thread::hardware_concurrency();
       if (v > 8) v = 8;
+      // a larger share granted through OMP_NUM_THREADS is taken (up to 32); a smaller value is not a limit meant for
+      // this library (torchrun sets it to 1 for every rank)
+      if (const char *e = getenv("OMP_NUM_THREADS")) {
+        int w = atoi(e);
+        if (w > v) v = w > 32 ? 32 : w;
+      }
     }
     return v < 1 ? 1 : v;
   }();
