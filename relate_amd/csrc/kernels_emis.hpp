@@ -241,6 +241,13 @@ __global__ void table_ld_kernel(const int *__restrict__ choose, const double *__
 __device__ inline int geno_at(const uint64_t *__restrict__ G, int W, int s, int ind) {
   return (int)((G[(size_t)s * W + (ind >> 5)] >> (2 * (ind & 31))) & 3u);
 }
+// genotype of SNP s in the individual-major copy (row of one individual: SNPs 32w .. 32w+31 per word, 2 bits each)
+__device__ inline int geno_row_at(const uint64_t *__restrict__ row, int s) {
+  return (int)((row[s >> 5] >> (2 * (s & 31))) & 3u);
+}
+__device__ inline uint64_t kept_bits(uint64_t a, uint64_t b) {  // bit 2k set iff SNP k of the word is non-missing in both
+  return (a | (a >> 1)) & (b | (b >> 1)) & 0x5555555555555555ull;
+}
 
 // K4: front half of sgl (which_arent_NA, diff, errorNoLD/emission2_new, remove_cross, getHighestId, LD2_new;
 // src/relateHMM.cpp:3424-3472) for a block of P pairs, any back2.  Workgroup = one wave = 64 consecutive pairs x one
@@ -259,23 +266,34 @@ struct SlowItem {
   double t, e0, e1, e2;
 };
 template <bool FULL>
-__device__ inline SlowItem stage_slow_item(const uint64_t *__restrict__ G, int M, int W, int i1, int i2, int s,
+__device__ inline SlowItem stage_slow_item(const uint64_t *__restrict__ Gt, int Wt, int M, int i1, int i2, int s,
                                            const double *__restrict__ pos, const double *__restrict__ mea,
                                            const double *__restrict__ pBA, const double *__restrict__ pbA,
                                            const double *__restrict__ pBa, const double *__restrict__ pba, int back,
                                            int back2, double eps) {
   SlowItem R{2, 0.0, 1.0, 1.0, 1.0};
-  const int g1 = geno_at(G, W, s, i1), g2 = geno_at(G, W, s, i2);
-  // rows r = 0..back-1 <-> r-th previous kept SNP at distance dd = s-1-s_prev (< back2)
-  int bestS = -1, nfound = 0;  // bestS: SNP of the first row with the strictly largest measure
+  const uint64_t *r1 = Gt + (size_t)i1 * Wt, *r2 = Gt + (size_t)i2 * Wt;
+  const int g1 = geno_row_at(r1, s), g2 = geno_row_at(r2, s);
+  // rows r = 0..back-1 <-> r-th previous kept SNP at distance dd = s-1-s_prev (< back2).  The kept SNPs before s are
+  // the set bits of the two rows' words, taken from s-1 downwards: a handful of word loads in place of two genotype
+  // reads per depth.
+  int bestS = -1, nfound = 0, nearest = -1;  // bestS: SNP of the first row with the strictly largest measure
   double bv = 0;
-  for (int dd = 0; dd < back2 && nfound < back; dd++) {
-    int sp = s - 1 - dd;
-    if (sp < 0) break;
-    if (geno_at(G, W, sp, i1) == 0 || geno_at(G, W, sp, i2) == 0) continue;
-    double v = mea[(size_t)dd * (M - 1) + (s - 1)];
-    if (nfound == 0 || v > bv) { bv = v; bestS = sp; }
-    nfound++;
+  const int lowest = max(0, s - back2);  // SNPs below are beyond depth back2
+  for (int w = (s - 1) >> 5; w >= 0 && nfound < back && w * 32 + 31 >= lowest && s > 0; w--) {
+    uint64_t K = kept_bits(r1[w], r2[w]);
+    if (w == ((s - 1) >> 5) && ((s - 1) & 31) != 31) K &= ((uint64_t)1 << (2 * (((s - 1) & 31) + 1))) - 1;  // SNPs < s only
+    while (K && nfound < back) {
+      const int b = 63 - __clzll(K);  // highest set bit: the nearest kept SNP not yet taken
+      K &= ~((uint64_t)1 << b);
+      const int sp = w * 32 + (b >> 1);
+      if (sp < lowest) { K = 0; break; }
+      const int dd = s - 1 - sp;
+      double v = mea[(size_t)dd * (M - 1) + (s - 1)];
+      if (nfound == 0) nearest = sp;
+      if (nfound == 0 || v > bv) { bv = v; bestS = sp; }
+      nfound++;
+    }
   }
   if (nfound == 0) { bv = 0; bestS = -1; }
   if (nfound < back && 0.0 > bv) bestS = -1;  // a zero-filled row beyond the window wins (getHighestId, :492)
@@ -285,25 +303,27 @@ __device__ inline SlowItem stage_slow_item(const uint64_t *__restrict__ G, int M
     int dd = s - 1 - bestS;
     size_t at = (size_t)dd * M + s;
     double S[3], E[3];
-    emis_cond(pBA[at], pbA[at], pBa[at], pba[at], g1, g2, geno_at(G, W, bestS, i1), geno_at(G, W, bestS, i2), eps, S);
+    emis_cond(pBA[at], pbA[at], pBa[at], pba[at], g1, g2, geno_row_at(r1, bestS), geno_row_at(r2, bestS), eps, S);
     store_entry(E, S);
     R.e0 = E[0]; R.e1 = E[1]; R.e2 = E[2];
   }
   if (FULL) {  // the pair's own distance: to the last kept SNP before s (a slow item always has one)
-    for (int sp = s - 1; sp >= 0; sp--)
-      if (geno_at(G, W, sp, i1) && geno_at(G, W, sp, i2)) {
-        double d = pos[s] - pos[sp];
-        R.t = d < 0 ? 10000000.0 : d;
-        break;
-      }
+    int sp = nearest;
+    if (sp < 0)  // beyond depth back2: further down the rows
+      for (int q = lowest - 1; q >= 0; q--)
+        if (geno_row_at(r1, q) && geno_row_at(r2, q)) { sp = q; break; }
+    if (sp >= 0) {
+      double d = pos[s] - pos[sp];
+      R.t = d < 0 ? 10000000.0 : d;
+    }
   }
   return R;
 }
 
 template <bool FULL>
 __global__ void __launch_bounds__(64)
-stage_pairs_kernel(const uint64_t *__restrict__ G, int M, int W, const int32_t *__restrict__ pairs, int P,
-                   const double *__restrict__ pos, const double *__restrict__ tab1, const double *__restrict__ tabL,
+stage_pairs_kernel(const uint64_t *__restrict__ G, const uint64_t *__restrict__ Gt, int Wt, int M, int W,
+                   const int32_t *__restrict__ pairs, int P, const double *__restrict__ pos, const double *__restrict__ tab1, const double *__restrict__ tabL,
                    const int *__restrict__ chooseG, const double *__restrict__ mea, const double *__restrict__ pBA,
                    const double *__restrict__ pbA, const double *__restrict__ pBa, const double *__restrict__ pba,
                    int useLD, int back, int back2, double eps, double *__restrict__ rec, int RP, int col0,
@@ -390,7 +410,7 @@ stage_pairs_kernel(const uint64_t *__restrict__ G, int M, int W, const int32_t *
     unsigned long long m = masks[L];
     for (int k = j - offs[L]; k > 0; k--) m &= m - 1;
     const int s = s0 + (int)__ffsll((long long)m) - 1;
-    const SlowItem R = stage_slow_item<FULL>(G, M, W, ind[L][0], ind[L][1], s, pos, mea, pBA, pbA, pBa, pba, back, back2, eps);
+    const SlowItem R = stage_slow_item<FULL>(Gt, Wt, M, ind[L][0], ind[L][1], s, pos, mea, pBA, pbA, pBa, pba, back, back2, eps);
     ScaleAcc dummy;
     int nk = 0;
     put_record<FULL>(rec, RP, s, col0 + (blockIdx.x % groups) * 64 + L, R.state, R.t, R.e0, R.e1, R.e2, dummy, nk);

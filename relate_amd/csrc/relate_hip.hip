@@ -390,7 +390,7 @@ int stage_cols(relate_hip_t h, const int32_t *pairs, int n, int col0, int RP, bo
     static_assert(kStageRun == 64, "one bit per SNP of a run");
     const unsigned ggrid = (unsigned)((size_t)nruns * ((n + 63) / 64));
 #define STAGE_GEN(FULL)                                                                                               \
-  hipLaunchKernelGGL(stage_pairs_kernel<FULL>, dim3(ggrid), dim3(64), 0, h->stream, h->dG.p, h->M,                    \
+  hipLaunchKernelGGL(stage_pairs_kernel<FULL>, dim3(ggrid), dim3(64), 0, h->stream, h->dG.p, h->dGt.p, h->Wt, h->M,   \
                      h->W, h->dPairs.p, n, h->dPos.p, h->dTab1.p, h->dTabL.p, h->dChoose.p, h->dMea.p,                \
                      h->dPBA.p, h->dPbA.p, h->dPBa.p, h->dPba.p, h->useLD, h->o.back, h->back2, h->o.epsilon, R.p,    \
                      RP, col0, h->dScM.p, h->dScE.p, h->dScN.p)
@@ -1740,12 +1740,13 @@ int relate_hip_precalc(relate_hip_t h, int *keep_out, int *M_out) {
     size_t need = h->useLD ? (size_t)M * h->back2 * 243 * sizeof(double) : 0;
     h->winMode = h->back2 <= 32 && need <= freeb / 4;
   }
+  // individual-major copy of the genotypes: the windowed kernel's input, and the kept-SNP scans of the generic one
+  h->Wt = (M + 31) / 32;
+  PCHK(h->dGt.ensure((size_t)N * h->Wt));
+  hipLaunchKernelGGL(transpose_geno_kernel, dim3(blocks_for((long)N * h->Wt, 256)), dim3(256), 0, st, Gfinal, N, M, W,
+                     h->Wt, h->dGt.p);
+  PCHK(hipGetLastError());
   if (h->winMode) {
-    h->Wt = (M + 31) / 32;
-    PCHK(h->dGt.ensure((size_t)N * h->Wt));
-    hipLaunchKernelGGL(transpose_geno_kernel, dim3(blocks_for((long)N * h->Wt, 256)), dim3(256), 0, st, Gfinal, N, M, W,
-                       h->Wt, h->dGt.p);
-    PCHK(hipGetLastError());
     if (h->useLD) {
       PCHK(h->dTabD.ensure((size_t)M * h->back2 * 243));
       hipLaunchKernelGGL(table_ld_depth_kernel, dim3(blocks_for((long)M * h->back2 * 81, 256)), dim3(256), 0, st,
@@ -1758,7 +1759,6 @@ int relate_hip_precalc(relate_hip_t h, int *keep_out, int *M_out) {
     }
     h->dTabL.release();
   } else {
-    h->dGt.release();
     h->dTabD.release();
     if (h->useLD) {
       PCHK(h->dTabL.ensure((size_t)M * 243));
