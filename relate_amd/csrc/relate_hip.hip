@@ -933,10 +933,13 @@ struct FitPop {
     // The brackets of launch_like at long rows: <= 65 536 slots 43 ms, <= 98 304 60 ms, <= 131 072 68 ms,
     // <= 262 144 122 ms at M = 5e5.  A round that falls just above a bracket launches the bracket and holds the rest.
     long budget = want;
-    if (!first_round && long_rows) {
-      if (want > 2 * kTurn) budget = 2 * kTurn;
-      else if (want > kTurn && want < kTurn * 9 / 5) budget = kTurn;
-      else if (want > kTurn / 2 && want < kTurn * 11 / 16) budget = kTurn / 2;
+    if (long_rows) {
+      const long head = first_round ? 2L * P : 0;  // the uLike / poLike points of the first launch count towards its bracket
+      const long all = want + head;
+      if (all > 2 * kTurn) budget = 2 * kTurn - head;
+      else if (all > kTurn && all < kTurn * 9 / 5) budget = kTurn - head;
+      else if (all > kTurn / 2 && all < kTurn * 11 / 16) budget = kTurn / 2 - head;
+      if (budget < 0) budget = 0;
     }
     // Slots.  A lane of the likelihood kernels may carry nv points of one pair (pick_nv): every pair's points start at
     // a multiple of nv and are padded to one with copies of its last point (values never read); the budget counts
