@@ -40,6 +40,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "kernels_emis.hpp"
 
@@ -1057,15 +1058,16 @@ decode_bwd_kernel(const double *__restrict__ rec, const double *__restrict__ tsh
 // every state starts from max(log k) + its emission, :1356-1359).  bp: M x P bytes (3 x 2-bit back pointers).
 // The transition matrix is formed the reference's way (exp, constants, fix_underflow) because the tie rules act
 // on its logarithms.
-__device__ inline double vmax3(double a, double b, double c) {
-  if (a > b && a > c) return a;
-  else if (b > a && b > c) return b;
-  return c;
-}
 __device__ inline int vwhich3(double a, double b, double c) {
   if (a > b && a > c) return 0;
   else if (b > a && b > c) return 1;
   return 2;
+}
+// max3 (a > b && a > c ? a : b > a && b > c ? b : c) and which_max of the same three sums at once, without branches
+__device__ __forceinline__ double vpick3(double a, double b, double c, int &which) {
+  const bool fa = a > b && a > c, fb = b > a && b > c;
+  which = fa ? 0 : (fb ? 1 : 2);
+  return fa ? a : (fb ? b : c);
 }
 
 struct RefTrans {
@@ -1112,112 +1114,204 @@ __device__ inline void ref_trans_at(const RefTrans &C, double t, double (&T)[3][
   T[2][1] = t01; T[2][0] = t20; T[2][2] = (-t01 - t20) + 1;
 }
 
-// A workgroup takes kVitPairs pairs.  The expensive part of a step -- two exponentials and twelve logarithms, none of
-// which depends on the chain -- is done by all 256 threads for a tile of kVitTile SNPs at once (thread = one pair and one
-// SNP of the tile) and left in LDS; then one lane per pair walks the tile: nine adds, the max3 / which_max rules, one
-// back-pointer byte per SNP (0xFF = SNP dropped for the pair).  The same library calls on the same arguments as one lane
-// per pair would make, so the values, the ties and the paths are the same.  bp: (M + 1) x P bytes; row M holds the
-// state the path ends in (0xFF: the pair has no kept SNP).
-static constexpr int kVitPairs = 16, kVitTile = 16;
-__global__ void __launch_bounds__(256)
+// Back pointers of the Viterbi: one byte per pair and SNP (three two-bit choices, 0xFF = SNP dropped for the pair), and
+// the state the path ends in as the byte of "SNP" M.  Pairs go in groups of kVitPairs, and within a group four SNPs of
+// a pair lie together: [group][SNP / 4][pair % 16][SNP % 4] -- the walking wave of the forward kernel stores a dword per
+// pair and four SNPs (64 B per store for sixteen pairs), the backward kernel reads a stretch of a group as one run.
+static constexpr int kVitPairs = 16;
+__host__ __device__ inline size_t vit_bp_quads(int M) { return (size_t)M / 4 + 1; }
+__host__ __device__ inline size_t vit_bp_bytes(int M, int P) {
+  return (size_t)((P + kVitPairs - 1) / kVitPairs) * vit_bp_quads(M) * 64;
+}
+__host__ __device__ inline size_t vit_bp_off(int p, int s, int M) {
+  return ((size_t)(p / kVitPairs) * vit_bp_quads(M) + (s >> 2)) * 64 + (p % kVitPairs) * 4 + (s & 3);
+}
+
+// One value of a lane's quad (lanes 4q .. 4q + 3) to all four of its lanes.
+template <int K>
+__device__ __forceinline__ double quad_bcast(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, K * 0x55, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, K * 0x55, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <int K>
+__device__ __forceinline__ int quad_bcast(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, K * 0x55, 0xF, 0xF, true);
+}
+
+// A workgroup takes NP pairs.  The expensive part of a step -- two exponentials and twelve logarithms, none of which
+// depends on the chain -- is done by 256 threads for a tile of 256 / NP SNPs at once (thread = one pair and one SNP of
+// the tile; the records of the next tile are already on their way) and left in LDS.  A fifth wave walks the tile
+// before, a quad of lanes per pair: lane y of the quad holds the state y the step arrives in -- three adds, the max3 /
+// which_max rules, the emission -- and the quad's three new values go round by DPP; lane 0 writes the back-pointer
+// byte of the SNP (0xFF = SNP dropped for the pair).  Two tile buffers, so the walk over tile t - 1 runs beside the
+// logarithms of tile t.  The same library calls and the same sums in the same order as one lane per pair would make,
+// so the values, the ties and the paths are the same.  A workgroup's time is its walk along the row whatever NP is:
+// a short pair list takes NP = 4 (tiles of 64 SNPs, four times the workgroups).  bp: vit_bp_off() above; the end state
+// is 0xFF for a pair without a kept SNP.
+static constexpr int kVitThreads = 256 + 64;
+template <int NP>
+__global__ void __launch_bounds__(kVitThreads)
 viterbi_fwd_kernel(const double *__restrict__ rec, int M, int P, int RP, const double *__restrict__ params,
                    int double_recom, uint8_t *__restrict__ bp) {  // rec: the FULL format (t, S0, S1, S2 planes)
-  __shared__ double lg[kVitTile][12][kVitPairs + 1];
-  __shared__ unsigned char dropped[kVitTile][kVitPairs];
-  const int pp = threadIdx.x % kVitPairs, ss = threadIdx.x / kVitPairs;
-  const int p = blockIdx.x * kVitPairs + pp;
+  static_assert(NP == 4 || NP == 8 || NP == 16, "a quad of the walking wave per pair");
+  constexpr int kTile = 256 / NP;
+  // per SNP, pair and state y arrived in: {log S_y, log T[0][y], log T[1][y], log T[2][y]} -- what lane y of the quad reads
+  __shared__ __align__(16) double lg[2][kTile][NP][3][4];
+  __shared__ unsigned char dropped[2][kTile][NP];
+  const int tid = threadIdx.x, wl = tid - 256;
+  const bool producer = tid < 256;
+  const bool walker = !producer && wl < 4 * NP;
+  const int pp = producer ? tid % NP : (wl >> 2) % NP, ss = tid / NP;
+  const int y = wl & 3, yy = y < 3 ? y : 2;  // the fourth lane of a quad shadows the third; nothing of it is kept
+  const int p = blockIdx.x * NP + pp;
   const int pc = p < P ? p : P - 1;  // dead lanes shadow a valid pair and write nothing
   const double a = params[3 * pc], k2 = params[3 * pc + 1], k1 = params[3 * pc + 2];
   const double k0 = 1 - k2 - k1;
   const RefTrans C = make_ref_trans(a, k2, k1, k0, double_recom);
-  double v0 = 0, v1 = 0, v2 = 0;  // the walking lanes' chain (threads with ss == 0)
+  const double mx = fmax(log(k0), fmax(log(k1), log(k2)));
+  double v0 = 0, v1 = 0, v2 = 0, vy = 0;  // the walking lanes' chain; vy: the lane's own component
   bool started = false;
-  for (int s0 = 0; s0 < M; s0 += kVitTile) {
-    const int s = s0 + ss;
-    if (s < M) {
-      const double *row = rec + rec_off(s, pc, kRecPlanesFull, RP);
-      const double rt = row[0];
-      const bool dr = __builtin_signbit(rt);
-      dropped[ss][pp] = dr ? 1 : 0;
-      if (!dr) {
-        lg[ss][0][pp] = log(row[128]); lg[ss][1][pp] = log(row[256]); lg[ss][2][pp] = log(row[384]);
-        double T[3][3];
-        ref_trans_at(C, rt, T);
-#pragma unroll
-        for (int x = 0; x < 3; x++)
-#pragma unroll
-          for (int y = 0; y < 3; y++) lg[ss][3 + x * 3 + y][pp] = log(T[x][y]);
+  const int ntiles = (M + kTile - 1) / kTile;
+  double cur[4] = {-1, 0, 0, 0}, nxt[4] = {-1, 0, 0, 0};
+  if (producer && ss < M) {
+    const double *row = rec + rec_off(ss, pc, kRecPlanesFull, RP);
+    cur[0] = row[0]; cur[1] = row[128]; cur[2] = row[256]; cur[3] = row[384];
+  }
+  for (int t = 0; t <= ntiles; t++) {
+    if (producer) {
+      const int s = t * kTile + ss;
+      if (s + kTile < M) {
+        const double *row = rec + rec_off(s + kTile, pc, kRecPlanesFull, RP);
+        nxt[0] = row[0]; nxt[1] = row[128]; nxt[2] = row[256]; nxt[3] = row[384];
       }
-    }
-    __syncthreads();
-    if (ss == 0 && p < P) {
-      const int n = min(kVitTile, M - s0);
-      for (int u = 0; u < n; u++) {
-        uint8_t b = 0xFF;
-        if (!dropped[u][pp]) {
-          const double l0 = lg[u][0][pp], l1 = lg[u][1][pp], l2 = lg[u][2][pp];
-          if (!started) {
-            double mx = fmax(log(k0), fmax(log(k1), log(k2)));
-            v0 = mx + l0; v1 = mx + l1; v2 = mx + l2;
-            started = true;
-            b = 0;
-          } else {
-            double L[3][3];
+      if (s < M) {
+        const int w = t & 1;
+        const double rt = cur[0];
+        const bool dr = __builtin_signbit(rt);
+        dropped[w][ss][pp] = dr ? 1 : 0;
+        if (!dr) {
+          double T[3][3];
+          ref_trans_at(C, rt, T);
 #pragma unroll
-            for (int x = 0; x < 3; x++)
+          for (int j = 0; j < 3; j++) {
+            lg[w][ss][pp][j][0] = log(cur[1 + j]);
 #pragma unroll
-              for (int y = 0; y < 3; y++) L[x][y] = lg[u][3 + x * 3 + y][pp];
-            double n0 = l0 + vmax3(L[0][0] + v0, L[1][0] + v1, L[2][0] + v2);
-            double n1 = l1 + vmax3(L[0][1] + v0, L[1][1] + v1, L[2][1] + v2);
-            double n2 = l2 + vmax3(L[0][2] + v0, L[1][2] + v1, L[2][2] + v2);
-            int w0 = vwhich3(v0 + L[0][0], v1 + L[1][0], v2 + L[2][0]);
-            int w1 = vwhich3(v0 + L[0][1], v1 + L[1][1], v2 + L[2][1]);
-            int w2 = vwhich3(v0 + L[0][2], v1 + L[1][2], v2 + L[2][2]);
-            b = (uint8_t)(w0 | (w1 << 2) | (w2 << 4));
-            v0 = n0; v1 = n1; v2 = n2;
+            for (int x = 0; x < 3; x++) lg[w][ss][pp][j][1 + x] = log(T[x][j]);
           }
         }
-        bp[(size_t)(s0 + u) * P + p] = b;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) cur[j] = nxt[j];
+    } else if (walker && t > 0) {
+      const int r = (t - 1) & 1, s0 = (t - 1) * kTile;
+      const int n = min(kTile, M - s0);
+      uint8_t *out = bp + vit_bp_off(pc, s0, M);  // s0 is a multiple of four: byte u of the tile is out[(u / 4) * 64 + u % 4]
+      const bool writes = y == 0 && p < P;
+      unsigned quad = 0;  // the lane's part of the bytes of four SNPs, stored together
+      const unsigned f1 = y < 3 ? 1u << (2 * yy) : 0u, f2 = y < 3 ? 2u << (2 * yy) : 0u;
+      struct In { double e, L0, L1, L2; int dr; };
+      auto fetch = [&](int u) {
+        const double *q = &lg[r][u][pp][yy][0];
+        return In{q[0], q[1], q[2], q[3], dropped[r][u][pp]};
+      };
+      // general: the chain of a pair may still have to start (its first kept SNP takes max log k + log S)
+      auto step = [&](int u, const In &in, auto general) {
+        const bool kept = !in.dr;
+        // the lane's two bits of the byte (none from a quad's fourth lane): which_max of the same three sums, in place
+        const double sa = in.L0 + v0, sb = in.L1 + v1, sc = in.L2 + v2;
+        const bool fa = sa > sb && sa > sc, fb = sb > sa && sb > sc;
+        double nv = in.e + (fa ? sa : (fb ? sb : sc));
+        unsigned field = fa ? 0u : (fb ? f1 : f2);
+        if (decltype(general)::value) {
+          if (!started) { nv = mx + in.e; field = 0; }
+          started = started || kept;
+        }
+        field = kept ? field : 0xFFu;
+        vy = kept ? nv : vy;
+        v0 = quad_bcast<0>(vy); v1 = quad_bcast<1>(vy); v2 = quad_bcast<2>(vy);
+        // the quad's three fields meet at the store
+        if (decltype(general)::value) {
+          const unsigned byte = quad_bcast<0>((int)field) | quad_bcast<1>((int)field) | quad_bcast<2>((int)field);
+          if (writes) out[(u >> 2) * 64 + (u & 3)] = (uint8_t)byte;
+        } else {
+          quad |= field << (8 * (u & 3));
+          if ((u & 3) == 3) {
+            const unsigned all = quad_bcast<0>((int)quad) | quad_bcast<1>((int)quad) | quad_bcast<2>((int)quad);
+            if (writes) *reinterpret_cast<unsigned *>(out + (u >> 2) * 64) = all;
+            quad = 0;
+          }
+        }
+      };
+      if (n == kTile && __all(started)) {
+        In c = fetch(0);  // the LDS reads of a step are issued a step ahead of the chain
+#pragma unroll 4
+        for (int u = 0; u < kTile; u++) {
+          const In nx = fetch(u + 1 < kTile ? u + 1 : u);
+          step(u, c, std::false_type());
+          c = nx;
+        }
+      } else {
+        for (int u = 0; u < n; u++) step(u, fetch(u), std::true_type());
       }
     }
-    __syncthreads();
+    __syncthreads();  // tile t is complete, tile t - 1 is consumed: its buffer is the one tile t + 1 goes to
   }
-  if (ss == 0 && p < P) bp[(size_t)M * P + p] = started ? (uint8_t)vwhich3(v0, v1, v2) : (uint8_t)0xFF;
+  if (walker && y == 0 && p < P) bp[vit_bp_off(p, M, M)] = started ? (uint8_t)vwhich3(v0, v1, v2) : (uint8_t)0xFF;
 }
 
-// The walk back along the pointers, kVitPairs pairs per workgroup and kVitBack SNPs at a time: every thread fetches the
-// pointers of one SNP of the stretch into LDS, one lane per pair walks them, every thread writes one SNP of the
-// stretch of every pair's row (path: P x M, -1 where the SNP is dropped for the pair).
+// The walk back along the pointers, kVitPairs pairs per workgroup and kVitBack SNPs at a time: the stretch of the
+// group's pointers is one run of memory (16 B a thread into LDS), one lane per pair walks it -- straight-line steps, so
+// that the LDS reads run ahead of the chain -- and every thread writes one SNP of the stretch of every pair's row
+// (path: P x M, -1 where the SNP is dropped for the pair).
 static constexpr int kVitBack = 256;
 __global__ void __launch_bounds__(kVitBack)
 viterbi_back_kernel(const uint8_t *__restrict__ bp, int M, int P, int8_t *__restrict__ path) {
-  __shared__ unsigned char pt[kVitBack][kVitPairs];
-  __shared__ signed char out[kVitPairs][kVitBack + 4];
+  __shared__ __align__(16) unsigned char pt[kVitBack * kVitPairs];  // [SNP / 4][pair][SNP % 4], as in memory
+  __shared__ __align__(4) signed char out[kVitPairs][kVitBack + 4];
+  const int tid = threadIdx.x;
   const int p0 = blockIdx.x * kVitPairs, np = min(kVitPairs, P - p0);
   int cur = 0;
-  if ((int)threadIdx.x < np) {
-    uint8_t e = bp[(size_t)M * P + p0 + threadIdx.x];
+  if (tid < np) {
+    uint8_t e = bp[vit_bp_off(p0 + tid, M, M)];
     cur = e == 0xFF ? -1 : (int)e;
   }
-  for (int hi = M; hi > 0; hi -= kVitBack) {
-    const int lo = max(0, hi - kVitBack), n = hi - lo;
-    if ((int)threadIdx.x < n) {
-      const uint8_t *q = bp + (size_t)(lo + threadIdx.x) * P + p0;
-      for (int j = 0; j < np; j++) pt[threadIdx.x][j] = q[j];
-    }
+  const int top = (M - 1) / kVitBack * kVitBack;
+  auto stretch = [&](int lo) {  // the thread's 16 B of the stretch that starts at SNP lo (whole quads: the buffer holds them)
+    const int n = min(kVitBack, M - lo);
+    return tid * 16 < (n + 3) / 4 * 64 ? reinterpret_cast<const uint4 *>(bp + vit_bp_off(p0, lo, M))[tid] : uint4{0, 0, 0, 0};
+  };
+  uint4 ahead = stretch(top);
+  for (int lo = top; lo >= 0; lo -= kVitBack) {
+    const int n = min(kVitBack, M - lo);
+    reinterpret_cast<uint4 *>(pt)[tid] = ahead;
     __syncthreads();
-    if ((int)threadIdx.x < np) {
-      const int j = threadIdx.x;
-      for (int u = n - 1; u >= 0; u--) {
-        const unsigned b = pt[u][j];
-        if (b == 0xFF) { out[j][u] = -1; continue; }
-        out[j][u] = (signed char)cur;
-        cur = (b >> (2 * cur)) & 3;
+    if (lo > 0) ahead = stretch(lo - kVitBack);  // on its way during the walk
+    if (tid < np) {
+      // four SNPs of the pair are one dword of the stretch; the next dword is on its way while the chain works through this one
+      const unsigned *pt32 = reinterpret_cast<const unsigned *>(pt);
+      unsigned *out32 = reinterpret_cast<unsigned *>(&out[tid][0]);
+      const int nq = (n + 3) / 4;
+      unsigned wnext = pt32[(nq - 1) * kVitPairs + tid];
+      for (int qd = nq - 1; qd >= 0; qd--) {
+        const unsigned wd = wnext;
+        wnext = pt32[(qd > 0 ? qd - 1 : 0) * kVitPairs + tid];
+        unsigned o = 0;
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+          unsigned b = (wd >> (8 * k)) & 0xFF;
+          if (4 * qd + k >= n) b = 0xFF;  // past the end of the rows: whatever the byte holds, it is no SNP
+          const bool dr = b == 0xFF;
+          o |= (dr ? 0xFFu : (unsigned)cur) << (8 * k);
+          cur = dr ? cur : (int)((b >> (2 * (cur & 3))) & 3);
+        }
+        out32[qd] = o;
       }
     }
     __syncthreads();
-    if ((int)threadIdx.x < n)
-      for (int j = 0; j < np; j++) path[(size_t)(p0 + j) * M + lo + threadIdx.x] = out[j][threadIdx.x];
+    if (tid < n)
+      for (int j = 0; j < np; j++) path[(size_t)(p0 + j) * M + lo + tid] = out[j][tid];
     __syncthreads();
   }
 }

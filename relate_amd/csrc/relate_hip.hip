@@ -1340,10 +1340,15 @@ int decode_block(relate_hip_t h, const int32_t *pairs, int p0, int P, const doub
   if (path) {
     int rc = stage_block(h, pairs, P, true);  // the Viterbi works on log S of every state: full format, own buffer
     if (rc) return rc;
-    HIPCHK(h, h->dBp.ensure((size_t)(M + 1) * P));
+    HIPCHK(h, h->dBp.ensure(vit_bp_bytes(M, P)));
     HIPCHK(h, h->dPath.ensure((size_t)M * P));
-    hipLaunchKernelGGL(viterbi_fwd_kernel, dim3(blocks_for(P, kVitPairs)), dim3(256), 0, h->stream, h->dRecV.p, M, P,
-                       h->recPitchV, h->dParams.p, h->o.double_recom, h->dBp.p);
+    // a workgroup's time is its walk along the row whatever the number of pairs it holds: a short pair list goes out four
+    // or eight pairs to a workgroup (tiles of 64 / 32 SNPs) so that every CU has workgroups, a long one sixteen (tiles of 16)
+    static const int vit_np = [] { const char *e = getenv("RELATE_VIT_NP"); return e ? atoi(e) : 0; }();
+    const int np = vit_np == 4 || vit_np == 8 || vit_np == 16 ? vit_np : P >= 8192 ? 16 : P >= 3072 ? 8 : 4;
+    auto vit = np == 16 ? viterbi_fwd_kernel<16> : np == 8 ? viterbi_fwd_kernel<8> : viterbi_fwd_kernel<4>;
+    hipLaunchKernelGGL(vit, dim3(blocks_for(P, np)), dim3(kVitThreads), 0, h->stream, h->dRecV.p, M, P, h->recPitchV,
+                       h->dParams.p, h->o.double_recom, h->dBp.p);
     HIPCHK(h, hipGetLastError());
     hipLaunchKernelGGL(viterbi_back_kernel, dim3(blocks_for(P, kVitPairs)), dim3(kVitBack), 0, h->stream, h->dBp.p, M, P,
                        h->dPath.p);
