@@ -361,6 +361,37 @@ def test_result_copy_paths_agree(gpu):
         gpu.decode(pairs, par, out=pin[:50])
 
 
+def test_viterbi_workgroup_shapes_give_the_same_paths(gpu, oracle):
+    """The forward kernel of the Viterbi takes 4, 8 or 16 pairs a workgroup by the length of the pair list (tiles of 64,
+    32, 16 SNPs); the walk back takes stretches of 256 SNPs.  One pair list through all three, on a marker count that
+    leaves a ragged last tile and stretch (1 337 = 5 x 256 + 57 = 20 x 64 + 57) with 3 % of the genotypes missing:
+    every path identical, pair by pair, and a sample of them identical to the oracle's (reference rules)."""
+    from relate_amd import synth
+    N, M = 130, 1337
+    g, pos, chr_, _ = synth.make_dataset(N, M, nchr=3, n_related=20, seed=31, miss=0.03)
+    opt = dict(pc.options("options.all.pair.txt"))
+    p = pc.oracle_precalc(oracle, g, pos, opt)
+    gpu.init_globals(g, pos, chr_, opt)
+    pairs = synth.all_pairs(N)
+    assert len(pairs) >= 8192                                   # 16 pairs a workgroup
+    rng = np.random.default_rng(8)
+    par = np.stack([rng.uniform(0.01, 0.2, len(pairs)), rng.uniform(0, 0.3, len(pairs)),
+                    rng.uniform(0.05, 0.6, len(pairs))], axis=1)
+    par[::7, 1] = 0.0                                           # k2 = 0 rows
+    _, wide, ns = gpu.decode(pairs, par, want_post=False, want_path=True)
+    _, mid, ns8 = gpu.decode(pairs[:5000], par[:5000], want_post=False, want_path=True)   # 8 pairs a workgroup
+    assert np.array_equal(mid, wide[:5000]) and np.array_equal(ns8, ns[:5000])
+    for lo in (0, 4990, 8000):                                  # 4 pairs a workgroup, ragged last group of pairs
+        _, few, _ = gpu.decode(pairs[lo:lo + 203], par[lo:lo + 203], want_post=False, want_path=True)
+        assert np.array_equal(few, wide[lo:lo + 203])
+    for n in (0, 1, 17, 4999, 5001, 8191, 8192, len(pairs) - 1):
+        i, j = pairs[n]
+        st = pc.oracle_stage(oracle, p, opt, int(i), int(j))
+        idx = np.where(st["keep"] == 1)[0]
+        assert ns[n] == st["m"] and (wide[n][st["keep"] == 0] == -1).all()
+        assert np.array_equal(wide[n][idx], oracle.viterbi(par[n], *st["Sk"], st["t"], 0))
+
+
 @pytest.mark.parametrize("rows", [1, 2, 3])
 def test_decode_f32_is_the_double_decode_rounded_once(gpu, rows):
     """relate_hip_decode_f32: the posterior rows in the .post writer's order (IBD0, IBD1, IBD2), the first `rows` of
