@@ -999,8 +999,8 @@ decode_bwd_kernel(const double *__restrict__ rec, const double *__restrict__ tsh
     b0 = bend[at]; b1 = bend[at + 1]; b2 = bend[at + 2];
   }
   const RecCol col(rec, tsh, own, RP, col0 + pc, M);
-  // The records and the checkpoint of the NEXT tile are fetched before this tile is worked on: the kernel holds one
-  // wave per SIMD (362 VGPRs), so nothing else would cover its memory latency while it computes.
+  // The records and the checkpoint of the NEXT tile are fetched before this tile is worked on: the kernel holds one or
+  // two waves per SIMD (228 VGPRs, 26 KB of LDS a wave), so little else would cover its memory latency while it computes.
   auto load_tile = [&](int tb, Rec (&R)[kTile], ChunkProd &X) {
 #pragma unroll
     for (int u = 0; u < kTile; u += 2) col.at2(min((tb + u) >> 1, col.hmax), R[u], R[u + 1]);
