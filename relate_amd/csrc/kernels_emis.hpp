@@ -261,6 +261,7 @@ __device__ inline uint64_t kept_bits(uint64_t a, uint64_t b) {  // bit 2k set if
 // and taken 64 at a time, whichever lane they came from; their S0 factors go through LDS back to the owning lane, which
 // folds them into its product in SNP order.
 static constexpr int kStageRun = 64;
+static constexpr int kSlowBuf = 1024;  // S0 factors of slow items in LDS at a time (a workgroup has up to 64 x kStageRun)
 struct SlowItem {
   int state;
   double t, e0, e1, e2;
@@ -268,6 +269,7 @@ struct SlowItem {
 template <bool FULL>
 __device__ inline SlowItem stage_slow_item(const uint64_t *__restrict__ Gt, int Wt, int M, int i1, int i2, int s,
                                            const double *__restrict__ pos, const double *__restrict__ mea,
+                                           const int *__restrict__ chooseG,
                                            const double *__restrict__ pBA, const double *__restrict__ pbA,
                                            const double *__restrict__ pBa, const double *__restrict__ pba, int back,
                                            int back2, double eps) {
@@ -280,9 +282,30 @@ __device__ inline SlowItem stage_slow_item(const uint64_t *__restrict__ Gt, int 
   int bestS = -1, nfound = 0, nearest = -1;  // bestS: SNP of the first row with the strictly largest measure
   double bv = 0;
   const int lowest = max(0, s - back2);  // SNPs below are beyond depth back2
+  // The measures of the depths 0 .. back-1 have a known winner, the global choice c = chooseG[s] (the first strictly
+  // largest of them): when the SNP at depth c is kept by the pair, it is also the first strictly largest among the kept
+  // ones of those depths, and only the depths from `back` on -- as many as SNPs were dropped above them, one or two --
+  // have to be read and compared.  Otherwise (the winner itself is dropped; 2-4 % of the slow items) every depth is read.
+  const int c = s > 0 ? chooseG[s] : -1;
+  const int spc = s - 1 - c;
+  const bool quick = c >= 0 && spc >= 0 && geno_row_at(r1, spc) && geno_row_at(r2, spc);
+  const int skip_above = quick ? max(s - back, 0) : s;  // SNPs skip_above .. s-1 are counted, not read
+  if (quick) { bv = mea[(size_t)c * (M - 1) + (s - 1)]; bestS = spc; }
   for (int w = (s - 1) >> 5; w >= 0 && nfound < back && w * 32 + 31 >= lowest && s > 0; w--) {
     uint64_t K = kept_bits(r1[w], r2[w]);
     if (w == ((s - 1) >> 5) && ((s - 1) & 31) != 31) K &= ((uint64_t)1 << (2 * (((s - 1) & 31) + 1))) - 1;  // SNPs < s only
+    if (K && nearest < 0) nearest = w * 32 + ((63 - __clzll(K)) >> 1);
+    if (w * 32 + 31 >= skip_above) {  // the part of the word at depths < back: every kept SNP there is a row, none wins
+      uint64_t top = K;
+      if (w * 32 < skip_above) {
+        const int cut = 2 * (skip_above - w * 32);  // bits from `cut` up belong to SNPs >= skip_above
+        top = K & ~(((uint64_t)1 << cut) - 1);
+        K &= ((uint64_t)1 << cut) - 1;
+      } else {
+        K = 0;
+      }
+      nfound += __popcll(top);  // (never more than back: the depths 0 .. back-1 hold at most back SNPs)
+    }
     while (K && nfound < back) {
       const int b = 63 - __clzll(K);  // highest set bit: the nearest kept SNP not yet taken
       K &= ~((uint64_t)1 << b);
@@ -290,8 +313,8 @@ __device__ inline SlowItem stage_slow_item(const uint64_t *__restrict__ Gt, int 
       if (sp < lowest) { K = 0; break; }
       const int dd = s - 1 - sp;
       double v = mea[(size_t)dd * (M - 1) + (s - 1)];
-      if (nfound == 0) nearest = sp;
-      if (nfound == 0 || v > bv) { bv = v; bestS = sp; }
+      if (bestS < 0 && nfound == 0) { bv = v; bestS = sp; }
+      else if (v > bv) { bv = v; bestS = sp; }
       nfound++;
     }
   }
@@ -329,7 +352,7 @@ stage_pairs_kernel(const uint64_t *__restrict__ G, const uint64_t *__restrict__ 
                    int useLD, int back, int back2, double eps, double *__restrict__ rec, int RP, int col0,
                    double *__restrict__ sc_m, int *__restrict__ sc_e, int *__restrict__ sc_n) {
   // pair p of the list goes to column col0 + p of the block
-  __shared__ double slow_s0[64 * kStageRun];
+  __shared__ double slow_s0[kSlowBuf];
   __shared__ unsigned long long masks[64];
   __shared__ int offs[65], ind[64][2];
   const int groups = (P + 63) / 64;
@@ -400,29 +423,35 @@ stage_pairs_kernel(const uint64_t *__restrict__ G, const uint64_t *__restrict__ 
   }
   __syncthreads();
   const int total = offs[64];
-  for (int j = lane; j < total; j += 64) {
-    int lo = 0, hi = 64;  // the lane L with offs[L] <= j < offs[L + 1]
-    while (hi - lo > 1) {
-      int mid = (lo + hi) >> 1;
-      if (offs[mid] <= j) lo = mid; else hi = mid;
+  const int n = __popcll(slow), at = offs[lane];
+  int k = 0;  // the lane's slow items folded so far
+  for (int base = 0; base < total; base += kSlowBuf) {  // (one round, but for runs with over a quarter of slow items)
+    const int end = min(total, base + kSlowBuf);
+    for (int j = base + lane; j < end; j += 64) {
+      int lo = 0, hi = 64;  // the lane L with offs[L] <= j < offs[L + 1]
+      while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (offs[mid] <= j) lo = mid; else hi = mid;
+      }
+      const int L = lo;
+      unsigned long long m = masks[L];
+      for (int q = j - offs[L]; q > 0; q--) m &= m - 1;
+      const int s = s0 + (int)__ffsll((long long)m) - 1;
+      const SlowItem R = stage_slow_item<FULL>(Gt, Wt, M, ind[L][0], ind[L][1], s, pos, mea, chooseG, pBA, pbA, pBa, pba, back, back2, eps);
+      ScaleAcc dummy;
+      int nk = 0;
+      put_record<FULL>(rec, RP, s, col0 + (blockIdx.x % groups) * 64 + L, R.state, R.t, R.e0, R.e1, R.e2, dummy, nk);
+      slow_s0[j - base] = R.state == 3 ? 0.0 : R.e0;
     }
-    const int L = lo;
-    unsigned long long m = masks[L];
-    for (int k = j - offs[L]; k > 0; k--) m &= m - 1;
-    const int s = s0 + (int)__ffsll((long long)m) - 1;
-    const SlowItem R = stage_slow_item<FULL>(Gt, Wt, M, ind[L][0], ind[L][1], s, pos, mea, pBA, pbA, pBa, pba, back, back2, eps);
-    ScaleAcc dummy;
-    int nk = 0;
-    put_record<FULL>(rec, RP, s, col0 + (blockIdx.x % groups) * 64 + L, R.state, R.t, R.e0, R.e1, R.e2, dummy, nk);
-    slow_s0[j] = R.state == 3 ? 0.0 : R.e0;
+    __syncthreads();
+    if (live)
+      for (; k < n && at + k < end; k++) {  // the lane's factors of this round, in SNP order
+        acc.m *= slow_s0[at + k - base];
+        if ((k & 7) == 7) acc.fold();
+      }
+    __syncthreads();
   }
-  __syncthreads();
   if (live) {
-    const int n = __popcll(slow), at = offs[lane];
-    for (int k = 0; k < n; k++) {
-      acc.m *= slow_s0[at + k];
-      if ((k & 7) == 7) acc.fold();
-    }
     acc.fold();
     sc_m[(size_t)c * RP + col0 + p] = acc.m;
     sc_e[(size_t)c * RP + col0 + p] = acc.e;
