@@ -366,49 +366,90 @@ stage_pairs_kernel(const uint64_t *__restrict__ G, const uint64_t *__restrict__ 
   int nkept = 0;
   unsigned long long slow = 0;
   if (live) {
+    // The two individuals' genotype words (individual-major copy) of the run and of the 64 SNPs below it, eight loads
+    // issued together: every genotype the fast items need while back <= 64 -- the SNP itself, the SNP its global
+    // choice conditions on, the state at the run's start -- then comes out of registers.  (s0 is a multiple of 64.)
+    const uint64_t *r1 = Gt + (size_t)i1 * Wt, *r2 = Gt + (size_t)i2 * Wt;
+    const int w0 = s0 >> 5;
+    uint64_t wa[4], wb[4];  // words w0 - 2 .. w0 + 1
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int w = w0 - 2 + k;
+      const bool in = w >= 0 && w < Wt;
+      wa[k] = in ? r1[w] : 0;
+      wb[k] = in ? r2[w] : 0;
+    }
     // state at the run's start: index of the last kept SNP before s0 (-1: none) and the number of consecutive kept SNPs
     // immediately before s0 (saturated at back)
-    int last = -1;
-    for (int s = s0 - 1; s >= 0; s--)
-      if (geno_at(G, W, s, i1) && geno_at(G, W, s, i2)) { last = s; break; }
-    int run = 0;
-    for (int s = s0 - 1; s >= 0 && run < back; s--) {
-      if (geno_at(G, W, s, i1) && geno_at(G, W, s, i2)) run++;
-      else break;
-    }
-    for (int s = s0; s < s1; s++) {
-      int g1 = geno_at(G, W, s, i1), g2 = geno_at(G, W, s, i2);
-      int state = 0;
-      double t = 0, e0 = 1, e1 = 1, e2 = 1;
-      if (g1 == 0 || g2 == 0) {
-        run = 0;
-      } else {
-        state = 2;
-        if (FULL && last >= 0) {  // else first kept SNP: t[0] = 0 in diff (:391-404); unconditional emission (LD2_new :2955-2957)
-          double d = pos[s] - pos[last];
-          t = d < 0 ? 10000000.0 : d;
+    int last = -1, run = 0;
+    {
+      const uint64_t E = 0x5555555555555555ull;
+      const uint64_t K1 = kept_bits(wa[1], wb[1]), K0 = kept_bits(wa[0], wb[0]);  // SNPs s0-32 .. s0-1, s0-64 .. s0-33
+      if (K1) last = s0 - 32 + ((63 - __clzll(K1)) >> 1);
+      else if (K0) last = s0 - 64 + ((63 - __clzll(K0)) >> 1);
+      else
+        for (int q = s0 - 65; q >= 0; q--)
+          if (geno_row_at(r1, q) && geno_row_at(r2, q)) { last = q; break; }
+      const uint64_t n1 = ~K1 & E, n0 = ~K0 & E;  // the SNPs not kept (words that do not exist count as such)
+      if (n1) run = 31 - ((63 - __clzll(n1)) >> 1);
+      else if (n0) run = 63 - ((63 - __clzll(n0)) >> 1);
+      else {
+        run = 64;
+        for (int q = s0 - 65; q >= 0 && run < back; q--) {
+          if (geno_row_at(r1, q) && geno_row_at(r2, q)) run++;
+          else break;
         }
-        if (!useLD || last < 0) {
-          const double *e = tab1 + ((size_t)s * 9 + (g1 - 1) * 3 + (g2 - 1)) * 3;
-          e0 = e[0]; e1 = e[1]; e2 = e[2];
-        } else if (run >= min(back, s)) {
-          int sc = s - 1 - chooseG[s];
-          int h1 = geno_at(G, W, sc, i1), h2 = geno_at(G, W, sc, i2);
-          int code = (((g1 - 1) * 3 + (g2 - 1)) * 3 + (h1 - 1)) * 3 + (h2 - 1);
-          const double *e = tabL + ((size_t)s * 81 + code) * 3;
-          e0 = e[0]; e1 = e[1]; e2 = e[2];
-        } else {
-          state = -1;  // slow: later, with the wave's other slow items
-          slow |= 1ull << (s - s0);
-        }
-        last = s;
-        if (run < back) run++;
       }
-      if (state >= 0) {
-        put_record<FULL>(rec, RP, s, col0 + p, state, t, e0, e1, e2, acc, nkept);
-        if ((s & 7) == 7) acc.fold();
-      } else {
-        nkept++;
+      if (run > back) run = back;
+    }
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const uint64_t ca = wa[2 + half], cb = wb[2 + half];
+      for (int s = s0 + 32 * half; s < min(s1, s0 + 32 * half + 32); s++) {
+        const int g1 = (int)((ca >> (2 * (s & 31))) & 3u), g2 = (int)((cb >> (2 * (s & 31))) & 3u);
+        int state = 0;
+        double t = 0, e0 = 1, e1 = 1, e2 = 1;
+        if (g1 == 0 || g2 == 0) {
+          run = 0;
+        } else {
+          state = 2;
+          if (FULL && last >= 0) {  // else first kept SNP: t[0] = 0 in diff (:391-404); unconditional emission (LD2_new :2955-2957)
+            double d = pos[s] - pos[last];
+            t = d < 0 ? 10000000.0 : d;
+          }
+          if (!useLD || last < 0) {
+            const double *e = tab1 + ((size_t)s * 9 + (g1 - 1) * 3 + (g2 - 1)) * 3;
+            e0 = e[0]; e1 = e[1]; e2 = e[2];
+          } else if (run >= min(back, s)) {
+            const int sc = max(s - 1 - chooseG[s], 0);
+            const int rel = sc - (s0 - 64);
+            int h1, h2;
+            if (rel >= 0) {
+              const int k = rel >> 5;
+              const uint64_t ha = k == 0 ? wa[0] : k == 1 ? wa[1] : k == 2 ? wa[2] : wa[3];
+              const uint64_t hb = k == 0 ? wb[0] : k == 1 ? wb[1] : k == 2 ? wb[2] : wb[3];
+              h1 = (int)((ha >> (2 * (rel & 31))) & 3u);
+              h2 = (int)((hb >> (2 * (rel & 31))) & 3u);
+            } else {  // back > 64
+              h1 = geno_row_at(r1, sc);
+              h2 = geno_row_at(r2, sc);
+            }
+            int code = (((g1 - 1) * 3 + (g2 - 1)) * 3 + (h1 - 1)) * 3 + (h2 - 1);
+            const double *e = tabL + ((size_t)s * 81 + code) * 3;
+            e0 = e[0]; e1 = e[1]; e2 = e[2];
+          } else {
+            state = -1;  // slow: later, with the wave's other slow items
+            slow |= 1ull << (s - s0);
+          }
+          last = s;
+          if (run < back) run++;
+        }
+        if (state >= 0) {
+          put_record<FULL>(rec, RP, s, col0 + p, state, t, e0, e1, e2, acc, nkept);
+          if ((s & 7) == 7) acc.fold();
+        } else {
+          nkept++;
+        }
       }
     }
     acc.fold();
