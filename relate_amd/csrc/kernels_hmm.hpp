@@ -1262,17 +1262,23 @@ viterbi_fwd_kernel(const double *__restrict__ rec, int M, int P, int RP, const d
 }
 
 // The walk back along the pointers, kVitPairs pairs per workgroup and kVitBack SNPs at a time: the stretch of the
-// group's pointers is one run of memory (16 B a thread into LDS), one lane per pair walks it -- straight-line steps, so
-// that the LDS reads run ahead of the chain -- and every thread writes one SNP of the stretch of every pair's row
-// (path: P x M, -1 where the SNP is dropped for the pair).
-static constexpr int kVitBack = 256;
+// group's pointers is one run of memory (16 B a thread into LDS).  A back-pointer byte is a map of the three states
+// (the identity where the SNP is dropped) and maps compose exactly, so the stretch of a pair is cut into 16 segments
+// of 16 SNPs: every thread composes the map of one segment of one pair, one lane per pair takes the state through the
+// 16 segment maps, and every thread walks its segment again from the state it is entered in -- 48 steps in a row
+// instead of 256.  Every thread then writes one SNP of the stretch of every pair's row (path: P x M, -1 where the SNP
+// is dropped for the pair).
+static constexpr int kVitBack = 256, kVitSeg = 16;
 __global__ void __launch_bounds__(kVitBack)
 viterbi_back_kernel(const uint8_t *__restrict__ bp, int M, int P, int8_t *__restrict__ path) {
+  static_assert(kVitBack == kVitPairs * kVitSeg && kVitBack / kVitSeg == 16, "a thread per pair and segment of 16 SNPs");
   __shared__ __align__(16) unsigned char pt[kVitBack * kVitPairs];  // [SNP / 4][pair][SNP % 4], as in memory
   __shared__ __align__(4) signed char out[kVitPairs][kVitBack + 4];
-  const int tid = threadIdx.x;
+  __shared__ unsigned char maps[kVitSeg][kVitPairs];
+  __shared__ signed char entry[kVitSeg][kVitPairs];
+  const int tid = threadIdx.x, j = tid % kVitPairs, g = tid / kVitPairs;
   const int p0 = blockIdx.x * kVitPairs, np = min(kVitPairs, P - p0);
-  int cur = 0;
+  int cur = 0;  // lanes 0 .. 15: the state of pair `tid` at the lowest SNP walked so far
   if (tid < np) {
     uint8_t e = bp[vit_bp_off(p0 + tid, M, M)];
     cur = e == 0xFF ? -1 : (int)e;
@@ -1288,30 +1294,55 @@ viterbi_back_kernel(const uint8_t *__restrict__ bp, int M, int P, int8_t *__rest
     reinterpret_cast<uint4 *>(pt)[tid] = ahead;
     __syncthreads();
     if (lo > 0) ahead = stretch(lo - kVitBack);  // on its way during the walk
-    if (tid < np) {
-      // four SNPs of the pair are one dword of the stretch; the next dword is on its way while the chain works through this one
-      const unsigned *pt32 = reinterpret_cast<const unsigned *>(pt);
-      unsigned *out32 = reinterpret_cast<unsigned *>(&out[tid][0]);
-      const int nq = (n + 3) / 4;
-      unsigned wnext = pt32[(nq - 1) * kVitPairs + tid];
-      for (int qd = nq - 1; qd >= 0; qd--) {
-        const unsigned wd = wnext;
-        wnext = pt32[(qd > 0 ? qd - 1 : 0) * kVitPairs + tid];
-        unsigned o = 0;
+    // the thread's segment: SNPs 16 g .. 16 g + 15 of pair j, four dwords of four SNPs
+    const unsigned *pt32 = reinterpret_cast<const unsigned *>(pt);
+    unsigned wd[4];
 #pragma unroll
-        for (int k = 3; k >= 0; k--) {
-          unsigned b = (wd >> (8 * k)) & 0xFF;
-          if (4 * qd + k >= n) b = 0xFF;  // past the end of the rows: whatever the byte holds, it is no SNP
-          const bool dr = b == 0xFF;
-          o |= (dr ? 0xFFu : (unsigned)cur) << (8 * k);
-          cur = dr ? cur : (int)((b >> (2 * (cur & 3))) & 3);
-        }
-        out32[qd] = o;
+    for (int i = 0; i < 4; i++) {
+      wd[i] = pt32[(4 * g + i) * kVitPairs + j];
+      if (n < kVitBack) {  // past the end of the rows: whatever the byte holds, it is no SNP
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (16 * g + 4 * i + k >= n) wd[i] |= 0xFFu << (8 * k);
+      }
+    }
+    unsigned f = 0x24;  // the map so far, from the segment's top downwards: f(x) in bits 2x, 2x + 1; identity to begin with
+#pragma unroll
+    for (int i = 3; i >= 0; i--)
+#pragma unroll
+      for (int k = 3; k >= 0; k--) {
+        const unsigned b = (wd[i] >> (8 * k)) & 0xFF;
+        const unsigned nf = ((b >> (2 * (f & 3))) & 3) | (((b >> (2 * ((f >> 2) & 3))) & 3) << 2) |
+                            (((b >> (2 * ((f >> 4) & 3))) & 3) << 4);
+        f = b == 0xFF ? f : nf;
+      }
+    maps[g][j] = (unsigned char)f;
+    __syncthreads();
+    if (tid < kVitPairs) {
+#pragma unroll
+      for (int q = kVitSeg - 1; q >= 0; q--) {
+        entry[q][tid] = (signed char)cur;
+        cur = cur < 0 ? cur : (int)((maps[q][tid] >> (2 * cur)) & 3);
       }
     }
     __syncthreads();
+    int c = entry[g][j];
+    unsigned *out32 = reinterpret_cast<unsigned *>(&out[j][0]);
+#pragma unroll
+    for (int i = 3; i >= 0; i--) {
+      unsigned o = 0;
+#pragma unroll
+      for (int k = 3; k >= 0; k--) {
+        const unsigned b = (wd[i] >> (8 * k)) & 0xFF;
+        const bool dr = b == 0xFF;
+        o |= (dr ? 0xFFu : (unsigned)c & 0xFFu) << (8 * k);
+        c = dr ? c : (int)((b >> (2 * (c & 3))) & 3);
+      }
+      out32[4 * g + i] = o;
+    }
+    __syncthreads();
     if (tid < n)
-      for (int j = 0; j < np; j++) path[(size_t)(p0 + j) * M + lo + tid] = out[j][tid];
+      for (int q = 0; q < np; q++) path[(size_t)(p0 + q) * M + lo + tid] = out[q][tid];
     __syncthreads();
   }
 }
