@@ -28,6 +28,11 @@ int relate_hip_bench_like(relate_hip_t h, const int32_t *pairs, int P, const dou
 int relate_hip_bench_decode(relate_hip_t h, const int32_t *pairs, int P, const double *params, int reps,
                             double *ms_fwd_out, double *ms_bwd_out);
 
+/* Ranks that took part in the handle's last relate_hip_gather: the size of the RCCL communicator as the library
+ * reports it (ncclCommCount), or the number of ranks of the file session; 0 before any gather.  Lets a scaling run
+ * show that the C-ABI collective really spanned N ranks. */
+int relate_hip_last_gather_ranks(relate_hip_t h);
+
 #ifdef __cplusplus
 }
 #endif

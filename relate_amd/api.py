@@ -116,6 +116,9 @@ def load_library():
     L.relate_hip_last_timings.argtypes = [vp, dp]
     L.relate_hip_last_chunks.argtypes = [vp, ip, ip]
     L.relate_hip_last_like_stats.argtypes = [vp, dp]
+    L.relate_hip_last_gather_ranks.argtypes = [vp]
+    L.relate_hip_gather.argtypes = [vp, C.POINTER(RelateFit), C.c_int64, C.c_int, C.c_int, C.c_char_p, C.c_int,
+                                    C.POINTER(RelateFit)]
     fpt = C.POINTER(C.c_float)
     L.relate_hip_linkage.argtypes = [vp, fpt, C.c_int, C.c_int, fpt, fpt, ip, C.c_int, C.POINTER(LinkageOpts), fpt, fpt,
                                      fpt, fpt, C.POINTER(LinkageResult)]
@@ -152,6 +155,30 @@ def rand_stream(seed, n):
     out = np.zeros(n, dtype=np.int32)
     L.relate_rand_stream(seed, n, out.ctypes.data_as(ip))
     return out
+
+
+def gather_records(handle, mine, P_total, rank, nranks, rendezvous, transport=0):
+    """relate_hip_gather: `mine` = this rank's RelateFit records (a ctypes array, or a structured numpy array of
+    fit_dtype()), in the order of its relate_hip_shard range; returns all P_total records as a ctypes array.
+    handle: a Relate (its GPU and stream carry the RCCL all-gather) or None (file transport only)."""
+    L = load_library()
+    if isinstance(mine, np.ndarray):
+        buf = (RelateFit * max(len(mine), 1)).from_buffer_copy(
+            np.ascontiguousarray(mine).tobytes().ljust(C.sizeof(RelateFit), b"\0"))
+    else:
+        buf = mine
+    out = (RelateFit * max(int(P_total), 1))()
+    h = handle.h if handle is not None else None
+    rc = L.relate_hip_gather(h, buf, int(P_total), rank, nranks,
+                             None if rendezvous is None else os.fsencode(rendezvous), transport, out)
+    if rc:
+        raise RelateError("relate_hip_gather: %s" % L.relate_hip_last_error(h).decode())
+    return out
+
+
+def fit_dtype():
+    """numpy view of relate_fit (include/relate_hip.h)."""
+    return np.dtype([(n, np.float64 if t is C.c_double else np.int32) for n, t in RelateFit._fields_])
 
 
 def shard(P, rank, nranks):
@@ -419,6 +446,10 @@ class Relate:
         self.L.relate_hip_last_like_stats(self.h, s.ctypes.data_as(dp))
         return dict(sweep_point_steps=s[0], chunked_point_steps=s[1], sweep_ms=s[2], chunked_ms=s[3],
                     sweep_launches=int(s[4]), chunked_launches=int(s[5]))
+
+    def gather_ranks(self):
+        """Ranks the last relate_hip_gather on this handle spanned (ncclCommCount, or the file session's size)."""
+        return int(self.L.relate_hip_last_gather_ranks(self.h))
 
     def last_chunks(self):
         a, b = C.c_int(0), C.c_int(0)

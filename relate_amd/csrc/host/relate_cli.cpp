@@ -547,7 +547,9 @@ int main(int argc, char **argv) {
     if (file_exists(kF)) std::printf("\t-> Filename: %s exists will append new results to file\n", kF.c_str());
     if (file_exists(postF)) std::printf("\t-> Filename: %s exists will append new results to file\n", postF.c_str());
   }
-  FILE *fpost = postF.empty() ? nullptr : std::fopen(postF.c_str(), "a");
+  // A rank's row shard starts empty: it must hold this run's rows and nothing else (rank r's rows are found by
+  // position in POSTOUTPUT.rank<r>).  The single-process file is appended to, under a name fresh_name made unused.
+  FILE *fpost = postF.empty() ? nullptr : std::fopen(postF.c_str(), nranks > 1 ? "w" : "a");
   FILE *fk = kF.empty() || rank > 0 ? nullptr : std::fopen(kF.c_str(), "a");
   FILE *fest = estF.empty() || rank > 0 ? nullptr : std::fopen(estF.c_str(), "w");
   if (rank > 0) { kF.clear(); estF.clear(); }

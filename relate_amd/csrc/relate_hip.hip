@@ -194,6 +194,7 @@ struct relate_hip_ctx {
   ncclComm_t comm = nullptr;  // relate_hip_gather: one communicator per handle, made at the first gather
   int comm_rank = -1, comm_n = 0;
   long gather_seq = 0;        // gathers issued on this handle (names the rendezvous files of each)
+  int gather_ranks_seen = 0;  // ranks the last gather's communicator (or file session) held: relate_hip_gather_ranks
   DBuf<unsigned char> dGatherS, dGatherR;
   unsigned char *scratch_dev = nullptr;  // device address of `scratch` on this handle's GPU (relate_hip_like_noalloc)
   long single_sweep_lanes = 45056;              // launches below this many lanes are cut along the SNP axis (pick_chunks)
@@ -2047,6 +2048,8 @@ int relate_hip_last_chunks(relate_hip_t h, int *like_chunks, int *decode_chunks)
   return RELATE_OK;
 }
 
+int relate_hip_last_gather_ranks(relate_hip_t h) { return h ? h->gather_ranks_seen : 0; }
+
 int relate_hip_bench_like(relate_hip_t h, const int32_t *pairs, int P, const double *params, int E, int reps,
                           double *ms_out) {
   int rc = require_ready(h);
@@ -2374,6 +2377,7 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;  // optional: how many ranks the communicator holds
   bool ok() const { return GetUniqueId && CommInitRank && CommDestroy && AllGather && GetErrorString; }
 };
 RcclApi &rccl() {
@@ -2394,6 +2398,7 @@ RcclApi &rccl() {
       a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.lib, "ncclCommDestroy");
       a.AllGather = (decltype(a.AllGather))dlsym(a.lib, "ncclAllGather");
       a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.lib, "ncclGetErrorString");
+      a.CommCount = (decltype(a.CommCount))dlsym(a.lib, "ncclCommCount");
     }
     return a;
   }();
@@ -2415,26 +2420,147 @@ bool write_file_atomically(const std::string &path, const void *data, size_t byt
   ok = (std::fclose(f) == 0) && ok;
   return ok && std::rename(tmp.c_str(), path.c_str()) == 0;
 }
-// waits until the file is there in full; seconds < 0 waits for ever
-bool read_file_when_ready(const std::string &path, void *data, size_t bytes, double seconds) {
-  auto t0 = std::chrono::steady_clock::now();
-  for (;;) {
-    struct stat st;
-    if (stat(path.c_str(), &st) == 0 && (size_t)st.st_size == bytes) {
-      FILE *f = std::fopen(path.c_str(), "rb");
-      if (f) {
-        bool ok = std::fread(data, 1, bytes, f) == bytes;
-        std::fclose(f);
-        if (ok) return true;
-      }
-    }
-    if (seconds >= 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
-    usleep(2000);
-  }
+// true when the file is there with exactly this size and was read in full
+bool read_file_exact(const std::string &path, void *data, size_t bytes) {
+  struct stat st;
+  if (stat(path.c_str(), &st) != 0 || (size_t)st.st_size != bytes) return false;
+  FILE *f = std::fopen(path.c_str(), "rb");
+  if (!f) return false;
+  bool ok = std::fread(data, 1, bytes, f) == bytes;
+  std::fclose(f);
+  return ok;
 }
 double gather_timeout() {
   const char *e = getenv("RELATE_GATHER_TIMEOUT");
   return e ? atof(e) : 1800.0;
+}
+
+// ---- rendezvous through files -----------------------------------------------------------------------------------
+// The ranks of a gather are separate processes that share nothing but a path.  Files of an earlier run under the same
+// path (a run that died, or a second run in the same directory) must never be taken for this run's, so every file
+// carries a nonce and the ranks first agree on a session:
+//   rank r > 0 writes  <base>.hello.<r> = {its fresh nonce};
+//   rank 0 writes      <base>.session   = {its fresh nonce0, state PROPOSE, the nonces it read, [ncclUniqueId]};
+//   rank r finds its own nonce echoed there (a session that lists another nonce for it is stale, or was made from a
+//   stale hello: it keeps waiting, rank 0 re-reads the hellos and proposes again) and writes <base>.ack.<r> =
+//   {nonce0, nonce_r};
+//   rank 0, holding every ack for (nonce0, nonce_r), rewrites the session with state GO; the ranks remove their hello
+//   and ack files and go on.  Every later file of the exchange carries nonce0; rank 0 removes them all at the end.
+constexpr uint64_t kRdvMagic = 0x333045544c4552ull;  // "RELTE03"
+struct RdvHello { uint64_t magic, nonce; };
+struct RdvAck { uint64_t magic, nonce0, nonce; };
+struct RdvMark { uint64_t magic, nonce0; int64_t count; };
+struct RdvSession {
+  uint64_t magic, nonce0;
+  int32_t state, nranks;  // state 0 = PROPOSE, 1 = GO
+  int64_t P_total;
+  unsigned char id[128];  // ncclUniqueId (transport 0)
+};
+static_assert(sizeof(ncclUniqueId) <= 128, "ncclUniqueId does not fit the session record");
+
+uint64_t fresh_nonce() {
+  uint64_t v = 0;
+  if (FILE *f = std::fopen("/dev/urandom", "rb")) {
+    if (std::fread(&v, 1, sizeof v, f) != sizeof v) v = 0;
+    std::fclose(f);
+  }
+  v ^= (uint64_t)getpid() << 32;
+  v ^= (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+  v ^= (uint64_t)std::chrono::system_clock::now().time_since_epoch().count() * 0x9e3779b97f4a7c15ull;
+  return v ? v : 1;
+}
+
+struct Deadline {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double seconds;
+  explicit Deadline(double s) : seconds(s) {}
+  bool over() const {
+    return seconds >= 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds;
+  }
+};
+
+// returns "" when the session stands (nonce0 and, if id is given, the ncclUniqueId: rank 0 supplies it, the others
+// receive it), or what went wrong
+std::string rendezvous_session(const std::string &base, int rank, int nranks, int64_t P_total, unsigned char *id,
+                               uint64_t *nonce0, const Deadline &dl) {
+  const size_t sbytes = sizeof(RdvSession) + sizeof(uint64_t) * (size_t)nranks;
+  std::vector<unsigned char> buf(sbytes);
+  RdvSession *S = (RdvSession *)buf.data();
+  uint64_t *nonces = (uint64_t *)(buf.data() + sizeof(RdvSession));
+  const std::string sess = base + ".session";
+  if (rank > 0) {
+    const std::string hello = base + ".hello." + std::to_string(rank), ack = base + ".ack." + std::to_string(rank);
+    RdvHello me{kRdvMagic, fresh_nonce()};
+    if (!write_file_atomically(hello, &me, sizeof me)) return "cannot write " + hello;
+    uint64_t acked = 0;
+    for (;;) {
+      if (read_file_exact(sess, buf.data(), sbytes) && S->magic == kRdvMagic && S->nranks == nranks &&
+          nonces[rank] == me.nonce) {
+        if (S->P_total != P_total)
+          return "the ranks disagree on the number of pairs (" + std::to_string((long long)S->P_total) + " on rank 0, " +
+                 std::to_string((long long)P_total) + " here)";
+        if (S->state == 1 && acked == S->nonce0) {
+          *nonce0 = S->nonce0;
+          if (id) std::memcpy(id, S->id, 128);
+          std::remove(hello.c_str());
+          std::remove(ack.c_str());
+          return "";
+        }
+        if (S->state == 0 && acked != S->nonce0) {
+          RdvAck a{kRdvMagic, S->nonce0, me.nonce};
+          if (!write_file_atomically(ack, &a, sizeof a)) return "cannot write " + ack;
+          acked = S->nonce0;
+        }
+      }
+      if (dl.over()) return "rank 0 did not open a session at " + sess;
+      usleep(2000);
+    }
+  }
+  std::vector<uint64_t> seen((size_t)nranks, 0);
+  std::memset(buf.data(), 0, sbytes);
+  S->magic = kRdvMagic;
+  S->nonce0 = *nonce0 = fresh_nonce();
+  S->nranks = nranks;
+  S->P_total = P_total;
+  if (id) std::memcpy(S->id, id, 128);
+  std::remove(sess.c_str());  // whatever an earlier run left
+  bool published = false;
+  for (;;) {
+    bool changed = false, all = true;
+    for (int r = 1; r < nranks; r++) {
+      RdvHello hl;
+      if (read_file_exact(base + ".hello." + std::to_string(r), &hl, sizeof hl) && hl.magic == kRdvMagic && hl.nonce &&
+          hl.nonce != seen[(size_t)r]) {
+        seen[(size_t)r] = hl.nonce;
+        changed = true;
+      }
+      all = all && seen[(size_t)r] != 0;
+    }
+    if (all && (changed || !published)) {
+      for (int r = 0; r < nranks; r++) nonces[r] = seen[(size_t)r];
+      S->state = 0;
+      if (!write_file_atomically(sess, buf.data(), sbytes)) return "cannot write " + sess;
+      published = true;
+    } else if (published) {
+      bool acked = true;
+      for (int r = 1; r < nranks && acked; r++) {
+        RdvAck a;
+        acked = read_file_exact(base + ".ack." + std::to_string(r), &a, sizeof a) && a.magic == kRdvMagic &&
+                a.nonce0 == S->nonce0 && a.nonce == seen[(size_t)r];
+      }
+      if (acked) {
+        S->state = 1;
+        if (!write_file_atomically(sess, buf.data(), sbytes)) return "cannot write " + sess;
+        return "";
+      }
+    }
+    if (dl.over()) {
+      for (int r = 1; r < nranks; r++)
+        if (!seen[(size_t)r]) return "rank " + std::to_string(r) + " did not arrive at " + base;
+      return "the ranks did not acknowledge the session at " + sess;
+    }
+    usleep(2000);
+  }
 }
 
 }  // namespace
@@ -2451,16 +2577,59 @@ extern "C" int relate_hip_gather(relate_hip_t h, const relate_fit *mine, int64_t
   relate_hip_shard(P_total, rank, nranks, &b, &e);
   const long seq = h ? h->gather_seq++ : 0;
   const std::string base = std::string(rendezvous ? rendezvous : "") + ".g" + std::to_string(seq);
+  const Deadline dl(gather_timeout());
+  if (h) h->gather_ranks_seen = 0;
   if (transport == 1) {
-    if (!write_file_atomically(base + ".fit." + std::to_string(rank), mine, sizeof(relate_fit) * (size_t)(e - b)))
-      return fail(h, RELATE_E_ARG, "cannot write " + base + ".fit." + std::to_string(rank));
+    if (nranks == 1) {
+      std::memcpy(all, mine, sizeof(relate_fit) * (size_t)(e - b));
+      if (h) h->gather_ranks_seen = 1;
+      return RELATE_OK;
+    }
+    uint64_t nonce0 = 0;
+    std::string err = rendezvous_session(base, rank, nranks, P_total, nullptr, &nonce0, dl);
+    if (!err.empty()) return fail(h, RELATE_E_ARG, err);
+    auto shard_file = [&](int r) { return base + ".fit." + std::to_string(r); };
+    auto done_file = [&](int r) { return base + ".done." + std::to_string(r); };
+    {
+      std::vector<unsigned char> out(sizeof(RdvMark) + sizeof(relate_fit) * (size_t)(e - b));
+      RdvMark mk{kRdvMagic, nonce0, e - b};
+      std::memcpy(out.data(), &mk, sizeof mk);
+      if (e > b) std::memcpy(out.data() + sizeof mk, mine, sizeof(relate_fit) * (size_t)(e - b));
+      if (!write_file_atomically(shard_file(rank), out.data(), out.size()))
+        return fail(h, RELATE_E_ARG, "cannot write " + shard_file(rank));
+    }
+    std::vector<unsigned char> in;
     for (int r = 0; r < nranks; r++) {
       int64_t rb = 0, re = 0;
       relate_hip_shard(P_total, r, nranks, &rb, &re);
-      if (!read_file_when_ready(base + ".fit." + std::to_string(r), all + rb, sizeof(relate_fit) * (size_t)(re - rb),
-                                gather_timeout()))
-        return fail(h, RELATE_E_ARG, "rank " + std::to_string(r) + " did not deliver " + base + ".fit." + std::to_string(r));
+      in.resize(sizeof(RdvMark) + sizeof(relate_fit) * (size_t)(re - rb));
+      for (;;) {  // a file of another session (an earlier run's) is not this rank's shard: wait for the real one
+        const RdvMark *mk = (const RdvMark *)in.data();
+        if (read_file_exact(shard_file(r), in.data(), in.size()) && mk->magic == kRdvMagic && mk->nonce0 == nonce0 &&
+            mk->count == re - rb)
+          break;
+        if (dl.over()) return fail(h, RELATE_E_ARG, "rank " + std::to_string(r) + " did not deliver " + shard_file(r));
+        usleep(2000);
+      }
+      if (re > rb) std::memcpy(all + rb, in.data() + sizeof(RdvMark), sizeof(relate_fit) * (size_t)(re - rb));
     }
+    RdvMark dn{kRdvMagic, nonce0, 0};
+    if (!write_file_atomically(done_file(rank), &dn, sizeof dn)) return fail(h, RELATE_E_ARG, "cannot write " + done_file(rank));
+    if (rank == 0) {  // every rank has read every shard: the files of this exchange go
+      for (int r = 1; r < nranks; r++)
+        for (;;) {
+          RdvMark m;
+          if (read_file_exact(done_file(r), &m, sizeof m) && m.magic == kRdvMagic && m.nonce0 == nonce0) break;
+          if (dl.over()) return fail(h, RELATE_E_ARG, "rank " + std::to_string(r) + " did not finish reading (" + done_file(r) + ")");
+          usleep(2000);
+        }
+      for (int r = 0; r < nranks; r++) {
+        std::remove(shard_file(r).c_str());
+        std::remove(done_file(r).c_str());
+      }
+      std::remove((base + ".session").c_str());
+    }
+    if (h) h->gather_ranks_seen = nranks;
     return RELATE_OK;
   }
   if (set_device(h)) return RELATE_E_HIP;
@@ -2471,19 +2640,29 @@ extern "C" int relate_hip_gather(relate_hip_t h, const relate_fit *mine, int64_t
     ncclResult_t r_ = (expr);                                                                         \
     if (r_ != ncclSuccess) return fail(h, RELATE_E_HIP, std::string(#expr) + ": " + N.GetErrorString(r_)); \
   } while (0)
+  bool made_session = false;
   if (!h->comm || h->comm_rank != rank || h->comm_n != nranks) {
     if (h->comm) { (void)N.CommDestroy(h->comm); h->comm = nullptr; }
     ncclUniqueId id;
+    unsigned char idbuf[128] = {0};
     if (rank == 0) {
       NCHK(N.GetUniqueId(&id));
-      if (nranks > 1 && !write_file_atomically(base + ".id", &id, sizeof(id)))
-        return fail(h, RELATE_E_ARG, "cannot write " + base + ".id");
-    } else if (!read_file_when_ready(base + ".id", &id, sizeof(id), gather_timeout())) {
-      return fail(h, RELATE_E_ARG, "rank 0 did not deliver " + base + ".id");
+      std::memcpy(idbuf, &id, sizeof id);
+    }
+    if (nranks > 1) {
+      uint64_t nonce0 = 0;
+      std::string err = rendezvous_session(base, rank, nranks, P_total, idbuf, &nonce0, dl);
+      if (!err.empty()) return fail(h, RELATE_E_ARG, err);
+      std::memcpy(&id, idbuf, sizeof id);
+      made_session = true;
     }
     NCHK(N.CommInitRank(&h->comm, nranks, id, rank));
     h->comm_rank = rank;
     h->comm_n = nranks;
+  }
+  {
+    int seen = 0;
+    if (N.CommCount && N.CommCount(h->comm, &seen) == ncclSuccess) h->gather_ranks_seen = seen;
   }
   // equal counts per rank: shards are padded to the longest one (they differ by at most one record)
   const size_t per = (size_t)((P_total + nranks - 1) / nranks) * sizeof(relate_fit);
@@ -2496,6 +2675,8 @@ extern "C" int relate_hip_gather(relate_hip_t h, const relate_fit *mine, int64_t
   HIPCHK(h, hipMemcpyAsync(host.data(), h->dGatherR.p, host.size(), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
 #undef NCHK
+  // the all-gather has completed here, so every rank has joined the communicator, i.e. has read the session
+  if (made_session && rank == 0) std::remove((base + ".session").c_str());
   for (int r = 0; r < nranks; r++) {
     int64_t rb = 0, re = 0;
     relate_hip_shard(P_total, r, nranks, &rb, &re);

@@ -120,10 +120,14 @@ class Oracle:
 
     @staticmethod
     def logs(S):
-        """(Sk1, Sk2, Sk3) = log of rows (2, 1, 0) as sgl forms them (src/relateHMM.cpp:3470-3472)."""
-        with np.errstate(divide="ignore"):
-            return (np.ascontiguousarray(np.log(S[2])), np.ascontiguousarray(np.log(S[1])),
-                    np.ascontiguousarray(np.log(S[0])))
+        """(Sk1, Sk2, Sk3) = log of rows (2, 1, 0) as sgl forms them (src/relateHMM.cpp:3470-3472), with the C
+        library's log as row_log has it (:410-423): numpy's vectorised log differs from it in the last bit for about
+        one value in a thousand, which is enough to send a run of the chaotic 2-parameter fit somewhere else."""
+        import math
+
+        def lg(row):
+            return np.array([math.log(v) if v > 0 else (-np.inf if v == 0 else np.nan) for v in row], dtype=np.float64)
+        return lg(S[2]), lg(S[1]), lg(S[0])
 
     def like(self, delta, Sk1, Sk2, Sk3, t, double_recom, alim1):
         d = np.ascontiguousarray(delta, dtype=np.float64)

@@ -63,12 +63,25 @@ def test_multistart_trajectories_equal_reference(oracle, bi):
             np.testing.assert_allclose(rows[:, :3], want[:, :3], rtol=tol_est, atol=1e-9)
 
 
-@pytest.mark.parametrize("optf,pairs", [("options.single.pair.txt", [(0, 1), (5, 12), (2, 9)]),
-                                        ("options.all.pair.txt", [(0, 1), (2, 9)]),
-                                        ("options.linkage.txt", [(0, 1), (5, 12)])])
-def test_multistart_bit_identical_with_reference_emissions(oracle, ref, optf, pairs):
+F32 = lambda v: float(np.float32(v))  # noqa: E731  (option values pass through float in the reference)
+BIT_CASES = [("options.single.pair.txt", {}, [(0, 1), (5, 12), (2, 9)]),
+             ("options.all.pair.txt", {}, [(0, 1), (2, 9)]),
+             ("options.linkage.txt", {}, [(0, 1), (5, 12)]),
+             # fixK2_fixA_fun / fixK2_fixA_optim (src/relateHMM.cpp:1783-1825): one free variable k1 in [0, 1], a and k2
+             # given; no option file of the reference selects it, so the options are set here (8 restarts, 2 to agree)
+             ("options.single.pair.txt", dict(fixK=1, fixK_val=0.0, fixA=1, fixA_val=F32(0.05), calcA=0, timesToRun=8),
+              [(0, 1), (5, 12), (2, 9)]),
+             ("options.single.pair.txt", dict(fixK=1, fixK_val=F32(0.1), fixA=1, fixA_val=F32(0.02), calcA=0,
+                                              timesToRun=8), [(0, 1), (3, 4)]),
+             # fixK2_fun with a = alim-bounded and k1 free (:1680-1732), k2 pinned at 0.05
+             ("options.single.pair.txt", dict(fixK=1, fixK_val=F32(0.05), fixA=0, calcA=0), [(0, 1), (5, 12)])]
+
+
+@pytest.mark.parametrize("optf,over,pairs", BIT_CASES,
+                         ids=["3 free", "calcA 2 free", "fixK2=0 calcA", "fixK2=0 fixA", "fixK2=0.1 fixA", "fixK2=0.05"])
+def test_multistart_bit_identical_with_reference_emissions(oracle, ref, optf, over, pairs):
     g, pos, chr_ = pc.dataset("dat_small")
-    opt = pc.options(optf)
+    opt = dict(pc.options(optf), **over)
     mode = pc.fit_mode(opt)
     seed = 977
     stream = relate_amd.rand_stream(seed, 800)
@@ -78,9 +91,10 @@ def test_multistart_bit_identical_with_reference_emissions(oracle, ref, optf, pa
             x = ref.sgl(i, j, seed=seed)
             Sk = oracle.logs(x["S"])
             starts = pc.draw_starts(stream, opt, x["timesRun"])
+            fk = opt["fixK_val"]
 
             def f(v):
-                return oracle.objective(mode, v, opt["fixA_val"], opt["fixK_val"], opt["phi"], *Sk, x["t"],
+                return oracle.objective(mode, v, opt["fixA_val"], fk, opt["phi"], *Sk, x["t"],
                                         opt["double_recom"], opt["alim1"])
             rows = []
             for r in range(x["timesRun"]):
@@ -91,9 +105,20 @@ def test_multistart_bit_identical_with_reference_emissions(oracle, ref, optf, pa
                 elif mode == 1:
                     v, nf = relate_amd.findmax_bfgs(f, [k2, k1], [0, 0], [1, 1])
                     rows.append([oracle.calculateA(1 - v[0] - v[1], v[1], v[0], opt["phi"]), v[0], v[1], -nf])
+                elif mode == 2:
+                    v, nf = relate_amd.findmax_bfgs(f, [a, k1], [opt["alim0"], 0], [opt["alim1"], 1])
+                    rows.append([v[0], fk, v[1], -nf])
+                elif mode == 3:
+                    lb = -2 * fk + 0.5 * np.sqrt(32 * fk - 16 * fk)
+                    v, nf = relate_amd.findmax_bfgs(f, [k1], [lb], [1])
+                    rows.append([oracle.calculateA(1 - v[0] - fk, v[0], fk, opt["phi"]), fk, v[0], -nf])
                 else:
                     v, nf = relate_amd.findmax_bfgs(f, [k1], [0.0], [1])
-                    rows.append([oracle.calculateA(1 - v[0], v[0], 0.0, opt["phi"]), 0.0, v[0], -nf])
-            assert np.array_equal(np.array(rows), x["conv"][:x["timesRun"]]), (optf, (i, j))
+                    rows.append([opt["fixA_val"], fk, v[0], -nf])
+            assert np.array_equal(np.array(rows), x["conv"][:x["timesRun"]]), (optf, over, (i, j))
+            # the restart rule on those rows gives sgl's answer
+            b, nr, nc = pc.multistart(np.array(rows)[:, 3].tolist() + [0.0] * 8, opt["timesToConverge"], x["timesRun"],
+                                      opt["convTol"])
+            assert (nr, nc) == (x["timesRun"], x["timesConv"]) and rows[b][3] == x["nll"]
     finally:
         ref.fini()

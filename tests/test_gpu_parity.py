@@ -16,9 +16,13 @@ Stated tolerances (north star: estimates / log-likelihoods 1e-6 relative in doub
       L-BFGS-B can take a different line-search branch; the estimates are then held to the floor the reference
       shows against itself across seeds (3.6 % in k1 in the 1-parameter mode, 1.4e-4 in the
       3-parameter mode) -> 5e-2 relative / 1e-3 absolute, and the posterior check is skipped for that pair.
-  2-parameter calcA mode (options.all.pair.txt): the reference does not reproduce itself across seeds
-  (-logL differs in the 4th digit); with a pinned seed the GPU run must reach a -logL within 2e-3
-  relative of the reference's and never worse than the reference's best by more than that.
+  2-parameter calcA mode (options.all.pair.txt): with a pinned seed the reference is deterministic, but under +-1 ulp
+  of noise in its objective it keeps fewer than one run in ten on its trajectory (tests/golden/sensitivity_allpair.json
+  and cli/c3_ref_fit.json, measured on the compiled reference by tests/golden/make_sensitivity_allpair.py).  The bars
+  come from that measurement (pathcheck.allpair_envelope): the fitted -logL may exceed the reference's by at most the
+  largest excess among the perturbed copies of the reference itself and undercut it by at most twice their largest
+  gain; a run that stayed on the reference's trajectory (-logL equal to 1e-9) has its (a, k2, k1) to 1e-6.  The
+  per-run comparison over all pairs of configs 2 and 3 is tests/test_gpu_sensitivity.py.
 """
 import numpy as np
 import pytest
@@ -28,6 +32,20 @@ import pathcheck as pc
 pytestmark = pytest.mark.gpu
 
 BLOCKS = list(range(4))
+_env = {}
+
+
+def allpair_env(data):
+    """(largest excess, largest gain) of the best-of-runs -logL among the perturbed copies of the reference."""
+    import json
+    import os
+    if data not in _env:
+        f = {"dat_small": "sensitivity_allpair.json", "500": os.path.join("cli", "c3_ref_fit.json")}[data]
+        with open(os.path.join(pc.GOLDEN, f)) as fh:
+            fx = json.load(fh)
+        e = pc.allpair_envelope(fx, pc.options(fx["options"]))
+        _env[data] = (float(e["best_excess"].max()), float(-e["best_excess"].min()), fx)
+    return _env[data]
 
 
 @pytest.fixture(scope="module")
@@ -120,9 +138,15 @@ def test_fit_pinned_seed_against_reference(gpu, prepared, bi):
         assert r["uLike"] == pytest.approx(f["uLike"], rel=1e-10)
         assert r["poLike"] == pytest.approx(f["poLike"], rel=1e-10)
         if two_par:
+            excess, gain, fx = allpair_env(b["data"])
             assert 1 <= r["timesRun"] <= opt["timesToRun"]  # the restart count follows the chaotic -logL values
-            assert r["negloglik"] == pytest.approx(f["nll"], rel=2e-3)
-            assert r["negloglik"] < min(f["uLike"], f["poLike"]) * (1 + 2e-3) or f["nll"] >= min(f["uLike"], f["poLike"])
+            d = r["negloglik"] / f["nll"] - 1
+            assert -2 * gain <= d <= excess, (rec["pair"], d)
+            runs = {tuple(p["pair"]): p["runs"] for p in fx["pairs"]}[tuple(rec["pair"])]
+            assert np.array_equal(np.array(runs[:f["timesRun"]]), np.array(rec["conv"]))   # two fixtures, one reference
+            for k in range(r["timesRun"]):
+                if abs(conv[n][k][3] / runs[k][3] - 1) <= 1e-9:
+                    np.testing.assert_allclose(conv[n][k][:3], runs[k][:3], rtol=1e-6, atol=1e-7)
         else:
             assert r["timesRun"] == f["timesRun"]
             assert r["timesConverged"] == f["timesConv"]

@@ -75,6 +75,57 @@ def test_linkage_mode_fit_sits_inside_the_references_own_one_ulp_envelope(gpu):
     np.testing.assert_allclose(ga[on], np.array([p["a"] for p in fx["pairs"]])[on], rtol=2e-4, atol=0)
 
 
+ALLPAIR = {"dat_small": os.path.join(HERE, "golden", "sensitivity_allpair.json"),
+           "500": os.path.join(HERE, "golden", "cli", "c3_ref_fit.json")}
+
+
+def test_allpair_fixtures_are_what_their_header_says():
+    """2-parameter calcA mode (options.all.pair.txt, configs 2 / 3 / 4): under +-1 ulp of noise in its objective the
+    reference keeps fewer than one run in ten on its trajectory, and the best of a pair's 8 runs moves for most pairs."""
+    for name, (P, on_lo, on_hi, ex_lo, ex_hi) in {"dat_small": (190, 100, 140, 3e-3, 4e-3),
+                                                   "500": (66, 40, 70, 1.5e-4, 2.5e-4)}.items():
+        with open(ALLPAIR[name]) as fh:
+            fx = json.load(fh)
+        e = pc.allpair_envelope(fx, pc.options(fx["options"]))
+        assert e["rel"].shape == (P, 8, 16) and fx["options"] == "options.all.pair.txt"
+        assert on_lo <= e["on"].min() and e["on"].max() <= on_hi
+        assert ex_lo < e["best_excess"].max() < ex_hi
+        for p in fx["pairs"]:   # sgl's result is the restart rule applied to the unperturbed rows
+            b, nr, nc = pc.multistart([r[3] for r in p["runs"]], 2, 8, 0.1)
+            assert (nr, nc, p["runs"][b][3]) == (p["timesRun"], p["timesConv"], p["nll"])
+
+
+@pytest.mark.parametrize("name", ["dat_small", "500"])
+def test_allpair_mode_fit_sits_inside_the_references_own_one_ulp_envelope(gpu, name):
+    """Configs 2 and 3 (and the mode of config 4) per RUN: the HIP fit's convInfo rows against the reference's, with
+    the bars of pathcheck.allpair_bars taken from the fixture's 16 perturbed copies of the reference itself."""
+    with open(ALLPAIR[name]) as fh:
+        fx = json.load(fh)
+    g, pos, chr_ = pc.dataset(name)
+    opt = dict(pc.options(fx["options"]), seed=fx["seed"], seed_mode=0)
+    assert gpu.init_globals(g, pos, chr_, opt) == fx["M"]
+    pairs = [tuple(p["pair"]) for p in fx["pairs"]]
+    res, conv = gpu.fit(pairs, want_conv=True)
+    assert all(r["status"] == 0 for r in res)
+    for r, p in zip(res, fx["pairs"]):
+        assert r["nsnp"] == p["m"]
+        assert r["uLike"] == pytest.approx(p["uLike"], rel=1e-12) and r["poLike"] == pytest.approx(p["poLike"], rel=1e-12)
+        assert r["a"] >= 0 and 0 <= r["k2"] <= 1 and 0 <= r["k1"] <= 1 and r["k1"] + r["k2"] <= 1 + 1e-12
+    st, fails = pc.allpair_bars(fx, opt, res, conv)
+    print("\n" + pc.allpair_line("%s, %d pairs" % (name, len(pairs)), st))
+    assert not fails, fails
+    # a pair whose every consumed run stayed on the reference's trajectory has the reference's result
+    same = 0
+    for n, (r, p) in enumerate(zip(res, fx["pairs"])):
+        if r["timesRun"] == p["timesRun"] and all(abs(conv[n][k][3] / p["runs"][k][3] - 1) <= 1e-9 for k in range(r["timesRun"])):
+            same += 1
+            assert r["timesConverged"] == p["timesConv"]
+            assert r["negloglik"] == pytest.approx(p["nll"], rel=1e-9)
+            for k in ("a", "k2", "k1"):
+                assert r[k] == pytest.approx(p[k], rel=1e-6, abs=1e-7), (p["pair"], k)
+    print("pairs with every run on the reference's trajectory (result = sgl's): %d" % same)
+
+
 def test_three_parameter_mode_every_keep_list_pair_follows_the_live_reference(gpu, ref):
     """options.single.pair.txt semantics (a, k2, k1 free; 3 restarts) on all 190 keep-list pairs of dat_small, the
     compiled reference run live with the same pinned seed: here the objective is curved at the optimum and every pair

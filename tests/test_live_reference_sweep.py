@@ -79,6 +79,11 @@ MODES = [
     ("fixK2=0: a, k1 free", dict(calcA=0, fixA=0, fixK=1, fixK_val=0.0), 6),
     ("fixK2=0 + calcA: k1 free", dict(calcA=1, fixA=0, fixK=1, fixK_val=0.0), 4),
     ("fixK2=0.1: a, k1 free", dict(calcA=0, fixA=0, fixK=1, fixK_val=F32(0.1)), 0),
+    # fixK2_fixA_fun / fixK2_fixA_optim (src/relateHMM.cpp:1783-1825): k1 alone is free, a and k2 are given
+    ("fixK2=0 + fixA=0.05: k1 free", dict(calcA=0, fixA=1, fixA_val=F32(0.05), fixK=1, fixK_val=0.0, timesToRun=8), 6),
+    ("fixK2=0.1 + fixA=0.02: k1 free", dict(calcA=0, fixA=1, fixA_val=F32(0.02), fixK=1, fixK_val=F32(0.1), timesToRun=8), 0),
+    # calcA_fun / calcA_optim (:1564-1621): k2 and k1 free, a = calculateA -- the mode of configs 2, 3 and 4
+    ("calcA: k2, k1 free", dict(calcA=1, fixA=0, fixK=0, timesToRun=8, alim1=1.0), 0),
 ]
 
 
@@ -114,7 +119,7 @@ def test_fit_modes(gpu, ref, mode):
                     assert r[k] == pytest.approx(x[k], rel=1e-6, abs=1e-7), k
                 idx = np.where(x["keep"] == 1)[0]
                 np.testing.assert_allclose(post[n][:, idx], x["post"], atol=1e-6)
-        print("\nfit %-28s objective at the reference's estimate maxrel %.1e; -logL reached maxrel %.2e; on the reference's "
+        print("\nfit %-30s objective at the reference's estimate maxrel %.1e; -logL reached maxrel %.2e; on the reference's "
               "trajectory %d/%d" % (name, obj, worst, on, len(pairs)))
         assert obj < 1e-12
         assert on >= min_on
