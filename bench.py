@@ -6,11 +6,14 @@ Workload (config.workload): the scale configuration of BASELINE.json (config 4: 
 of the hot path over one block of P pairs with the genotype matrix and all per-SNP tables resident in HBM:
     K4 stage_pairs  (per-pair emissions, front half of sgl)
     K5 like         (forward likelihood at E parameter points per pair = what one BFGS iterate requests)
-    K6 decode       (forward + backward sweep, posteriors written to HBM)
+    K6 decode       (forward + backward sweep, the two posterior rows the .post writer takes written to HBM)
 One HMM step = one update of the 3-state recursion for one (pair, SNP, evaluation point); a bench step therefore
-counts P * M * (E + 2) HMM steps (E forward evaluations, decode forward, decode backward).  Every rank owns a
-contiguous shard of the pair list (relate_hip_shard) and walks it block by block: weak scaling, no data-path
-collective; one RCCL all_gather of the per-pair results at the end.
+counts P * M * (E + 2) HMM steps (E forward evaluations, decode forward, decode backward) -- `value` is that blend,
+kept for continuity; SURVEY.md 8(d)'s three rates stand beside it at the top level of the line: like_point_steps_per_s
+(K5), decode_pair_snp_per_s (K6, forward + backward = one step) and end_to_end_pair_snp_per_s (the fit leg: what a
+user waits for).  Every rank owns a contiguous shard of the pair list (relate_hip_shard) and walks it block by block:
+weak scaling, no data-path collective; the path's one exchange, the all-gather of the per-pair result records, goes
+through the C ABI (relate_hip_gather over RCCL) and the line reports how many ranks its communicator held.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -32,22 +35,24 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3
 
 # Algorithmic bytes per (pair, SNP) of one launch by this design: emission record 16 B (two
 # planes: S1/S0, S2/S0; the distance of a step is the shared per-SNP one, M x 8 B for the whole block); packed genotypes
-# 2 x 2 bit; tile checkpoint 84 B per 16 SNPs; posterior 3 x 8 B.  The decode is two sweeps over the records: chunk
-# products + tile checkpoints, then the backward sweep that writes the posteriors.
+# 2 x 2 bit; tile checkpoint 84 B per 16 SNPs; posterior ROWS x 8 B (the rows the .post writer takes: IBD0 and IBD1 in
+# this mode, src/relateHMM.cpp:3771-3782).  The decode is two sweeps over the records: chunk products + tile
+# checkpoints, then the backward sweep that writes the posteriors.
 CKPT = 84.0 / 16
 REC = 16.0
+ROWS = 2
 
 
 def algorithmic_bytes(like_chunks, decode_chunks):
     return {"stage": REC + 0.5 + 0.25,
             "like": REC,
             "decode_fwd": REC + CKPT,
-            "decode_bwd": REC + CKPT + 24.0}
+            "decode_bwd": REC + CKPT + 8.0 * ROWS}
 
 
 # SURVEY.md section 8(d)'s figures, which price the path without materialised emissions: two 2-bit genotypes per forward
-# step (K5), plus the posterior rows for the decode (K6: 0.5 + 8 x rows, rows = 3 doubles here).
-SURVEY_BYTES = {"like": 0.5, "decode": 0.5 + 8.0 * 3}
+# step (K5), plus the posterior rows for the decode (K6: 0.5 + 8 x rows).
+SURVEY_BYTES = {"like": 0.5, "decode": 0.5 + 8.0 * ROWS}
 
 
 # Vector instructions per point-step of the likelihood kernels, counted by rocprofv3 (SQ_INSTS_VALU x 64 / point-steps;
@@ -217,8 +222,9 @@ def fit_leg(H, allp, npairs, M, first=0, note=None):
                          "sweep_ms": st["sweep_ms"], "chunked_ms": st["chunked_ms"],
                          "sweep_lane_steps": st["sweep_point_steps"], "chunked_lane_steps": st["chunked_point_steps"]},
             "note": note or "relate_hip_fit, options.all.pair.txt semantics (calcA, timesToRun 8: the 2-parameter mode whose "
-                    "estimates the reference itself does not reproduce across seeds, so its outputs are validated to -logL within "
-                    "2e-3 only); not part of value"}
+                    "runs the reference itself keeps on their trajectory in fewer than one case in ten under last-bit noise in "
+                    "its objective: validated per run against that measured envelope, tests/test_gpu_sensitivity.py); not "
+                    "part of value"}
 
 
 def opts_linkage():
@@ -332,26 +338,44 @@ def main():
         blk = mine[(i % nblocks) * P:(i % nblocks + 1) * P]
         ms_like = H.bench_like(blk, par, 1)      # stages the block (K4) then K5
         st_ms = H.timings()["stage_ms"]
-        f, bw = H.bench_decode(blk, par1, 1)     # K6 on the staged block
+        f, bw = H.bench_decode(blk, par1, 1, rows=ROWS)     # K6 on the staged block
         if record:
             sums["stage"] += st_ms
             sums["like"] += ms_like
             sums["decode_fwd"] += f
             sums["decode_bwd"] += bw
 
+    # The path's one exchange, through the C ABI: relate_hip_gather of the per-pair result records (here: one block's
+    # worth per rank) over RCCL on the handle's stream, its communicator made once per handle from a rendezvous file
+    # in a directory rank 0 names.  (Rehearsal on a one-GPU box: RCCL refuses two ranks on one device, so the records
+    # go through the file transport of the same entry point.)
+    from relate_amd import api
+    rdv = None
+    if dist is not None:
+        import tempfile
+        box = [tempfile.mkdtemp(prefix="relate_bench_rdv_") if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, device=torch.device(coll_dev if coll_dev == "cpu" else "cuda:%d" % local))
+        rdv = os.path.join(box[0], "rdv")
+    transport = 1 if (world > 1 and os.environ.get("RELATE_BENCH_ONE_GPU") == "1") else 0
+    recs = np.zeros(P, dtype=api.fit_dtype())
+    recs["negloglik"] = 1000.0 + rank
+    recs["nsnp"] = M
+
+    def exchange():
+        got = api.gather_records(H, recs, world * P, rank, world, rdv, transport)
+        assert got[(world - 1) * P].negloglik == 1000.0 + world - 1 and got[0].nsnp == M
+        return H.gather_ranks()
+
     for i in range(args.warmup):
         step(i, False)
+    exchange()                  # makes the communicator (once per handle, as in a scan)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i, True)
-    if dist is not None:
-        # the path's only exchange: gather of per-pair results (here: one value per pair of the last block)
-        res = torch.zeros(P, dtype=torch.float64, device=coll_dev)
-        out = [torch.zeros_like(res) for _ in range(world)]
-        dist.all_gather(out, res)
+    ranks_seen = exchange()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -382,33 +406,51 @@ def main():
         tr = sum(traffic[k] for k in tkey) if traffic and all(k in traffic for k in tkey) else None
         like_steps_s = P * M * E / (per["like"] * 1e-3)
         valu = VALU_PER_STEP[3 if lc > 1 else 1]
+        dec_ms = per["decode_fwd"] + per["decode_bwd"]
+        survey_gbs = SURVEY_BYTES["decode"] * units / (dec_ms * 1e-3) / 1e9
         line = {
             "metric": "pair x SNP fwd-bwd HMM steps/sec (node), all-pairs", "value": hmm_steps / dt,
             "unit": "pair*SNP HMM steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "value_note": "kernel-resident: posteriors stay in HBM.  With the 24 B of posterior rows per pair and SNP copied "
-                          "to the host the same step runs at 1.1-1.5e10 steps/s (PCIe; tools/pcie_rate.py, DESIGN.md section 6)",
+            "value_note": "the (E+2) blend of the step: E likelihood sweeps + decode forward + decode backward per (pair, SNP); "
+                          "SURVEY 8(d)'s three rates are like_point_steps_per_s, decode_pair_snp_per_s and "
+                          "end_to_end_pair_snp_per_s below.  Kernel-resident: posteriors stay in HBM; with the posterior rows "
+                          "copied to the host the step is PCIe-bound (tools/pcie_rate.py, DESIGN.md section 6)",
+            "like_point_steps_per_s": world * like_steps_s,
+            "decode_pair_snp_per_s": world * units / (dec_ms * 1e-3),
+            "end_to_end_pair_snp_per_s": None,
+            "gather": {"entry_point": "relate_hip_gather", "transport": "rccl" if transport == 0 else "file",
+                       "n_ranks_seen": ranks_seen, "records": world * P},
             "config": {"workload": "config 4 synthetic all-pairs, pair block per step: %d individuals x %d SNPs "
                                    "(%d after MAF filter), %d pairs/GPU/step, E=%d like points + decode, "
                                    "options.all.pair.txt semantics (calcA, back=5)" % (args.inds, args.snps, M, P, E),
                        "parallelism": "pair-block shards x%d" % world,
                        "snp_chunks": {"like": lc, "decode": dc}},
-            "roofline": {"bound": "hbm", "kernel": kernel_name[dom], "achieved": gbs[dom], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": gbs[dom] / HBM_PEAK_GBS, "traffic": tr,
-                         "algorithmic_bytes": BYTES[dom] * units,
-                         "algorithmic_bytes_survey": SURVEY_BYTES["decode"] * units,
-                         "frac_survey_decode": SURVEY_BYTES["decode"] * units
-                                               / ((per["decode_fwd"] + per["decode_bwd"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "K6 decode = chunk_matrix_kernel<false, true> + decode_combine_kernel + "
+                                                   "decode_bwd_kernel (dominant launch: %s)" % kernel_name[dom],
+                         "achieved": survey_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": survey_gbs / HBM_PEAK_GBS,
+                         "traffic": tr,
+                         "algorithmic_bytes": SURVEY_BYTES["decode"] * units,
+                         "algorithmic_bytes_per_pair_snp": SURVEY_BYTES["decode"],
+                         "decode_ms": dec_ms,
+                         "frac_design": gbs[dom] / HBM_PEAK_GBS, "achieved_design": gbs[dom],
+                         "algorithmic_bytes_design": BYTES[dom] * units,
                          "bytes_per_pair_snp_step": sum(BYTES.values()),
-                         "note": "dominant = the HBM-bound kernel with the largest share of the step (the likelihood kernels, a comparable share, are FP64-VALU-bound: roofline_fp64); traffic = HBM bytes per launch from the "
-                                 "committed PMC passes (profiles/pmc_traffic.json), null if they were taken on another "
-                                 "configuration.  The likelihood kernels are FP64-VALU-bound by design (two expm1 "
-                                 "per lane-step, 5 lanes share one 16 B record): see roofline_fp64"},
+                         "note": "achieved / frac price the whole K6 (both passes) at SURVEY 8(d)'s algorithmic bytes, "
+                                 "0.5 + 8 x rows per pair and SNP with rows = %d, over the HIP-event time of its launches; "
+                                 "frac_design = the dominant launch of the step among the HBM-bound ones on this design's own "
+                                 "bytes (materialised 16 B records, tile checkpoints); traffic = HBM bytes per launch of that "
+                                 "kernel from the committed PMC passes (profiles/pmc_traffic.json), null if they were taken on "
+                                 "another configuration.  The likelihood kernels are FP64-VALU-bound: roofline_fp64" % ROWS},
             "roofline_fp64": {"kernel": kernel_name["like"], "valu_insts_per_lane_step": valu,
                               "achieved": like_steps_s * valu / 1e12, "peak": FP64_LANE_OPS_PEAK / 1e12,
                               "unit": "T lane-instructions/s", "frac": like_steps_s * valu / FP64_LANE_OPS_PEAK,
-                              "lane_steps_per_s": like_steps_s},
+                              "frac_single_vector": like_steps_s * VALU_PER_STEP[1] / FP64_LANE_OPS_PEAK,
+                              "lane_steps_per_s": like_steps_s,
+                              "note": "frac counts every vector instruction of the route this launch takes (the chunked route "
+                                      "carries three row vectors per lane); frac_single_vector prices the same point-steps at the "
+                                      "27.3 instructions a single-vector sweep needs (about SURVEY 8(d)'s 15 FMA + 2 exp)"},
             "kernels_ms": per,
             "kernels_gbs": gbs,
             "kernels_hbm_frac": {k: v / HBM_PEAK_GBS for k, v in gbs.items()},
@@ -418,6 +460,7 @@ def main():
             line["linkage_mode"] = linkage_leg(local, args.inds, args.snps, all_pairs, min(args.linkage_pairs, len(all_pairs)))
         if world == 1 and not args.no_cpu and not args.no_fit:
             line["fit"] = fit_leg(H, mine, min(args.fit_pairs, len(mine)), M)
+            line["end_to_end_pair_snp_per_s"] = line["fit"]["pair_snp_per_s"]
             if args.fit_pairs > 0 and len(mine) >= 3 * args.fit_pairs + 4 * args.fit_pairs:
                 # what a scan's later blocks run at: a block of the size the records allow (twice the first one here), on
                 # the same handle, which has seen that first waves of restarts do not settle pairs in this mode
@@ -425,6 +468,7 @@ def main():
                                                  note="the next block of the same scan, twice the pairs: all restarts of a "
                                                       "pair start together from the first round (the handle's previous fit saw "
                                                       "that first waves do not settle pairs); not part of value")
+                line["end_to_end_pair_snp_per_s"] = line["fit_next_block"]["pair_snp_per_s"]
         if world == 1 and not args.no_cpu and not args.no_baseline:
             line["cpu_baseline"] = cpu_baseline(H, opt, E)
             line["cpu_baseline_all_cores"] = cpu_baseline_threads(H, opt, E)

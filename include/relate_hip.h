@@ -117,14 +117,17 @@ int relate_hip_pair_emissions(relate_hip_t h, int ind1, int ind2, int *keep, dou
 int relate_hip_like(relate_hip_t h, const int32_t *pairs /* P x 2 */, int P, const double *params, int E,
                     double *negloglik);
 
-/* relate_hip_like for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
- * that forbid hipMalloc).  No counterpart in the reference.  Works on the pair block the previous relate_hip_like /
- * fit / decode call staged (P must be that block's pair count), takes DEVICE pointers (d_params P x E x 3, pair-major
- * as relate_hip_like; d_negloglik P x E) and calls no hipMalloc / hipFree: the chunk products of a launch cut along
- * the SNP axis and the half vectors of the two-sided sweep go to a 64 MiB array every GPU the library runs on holds
- * until the process ends (a launch is cut into as many chunks as fit there; values agree with relate_hip_like to
- * rounding, <= 1e-13 relative).  At most 1 048 576 lanes (P x E) per call, more is rejected.  Returns with the values in
- * place.  Calls that overlap on one GPU (two handles, two threads) race on that array. */
+/* relate_hip_like for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc).  No
+ * counterpart in the reference.  Works on the pair block the previous relate_hip_like / decode call staged (P must be
+ * that block's pair count), takes DEVICE pointers (d_params P x E x 3, pair-major as relate_hip_like; d_negloglik
+ * P x E) and calls no hipMalloc / hipFree: the chunk products of a launch cut along the SNP axis and the half vectors
+ * of the two-sided sweep go to a 64 MiB array every GPU the library runs on holds until the process ends (a launch is
+ * cut into as many chunks as fit there; values agree with relate_hip_like to rounding, <= 1e-13 relative).  At most
+ * 1 048 576 lanes (P x E) per call, more is rejected.  Runs on the handle's own stream and returns with the values in
+ * place (it synchronises that stream, so it is not for use under stream capture).  A relate_hip_fit / run_pairs may
+ * leave NO block staged (its tail re-stages the last live pairs side by side): the call is then rejected with a
+ * message that names the staged pair count, and a relate_hip_like on the block stages it again.  Calls that overlap on
+ * one GPU (two handles, two threads) race on that array. */
 int relate_hip_like_noalloc(relate_hip_t h, int P, const double *d_params, int E, double *d_negloglik);
 
 /* run_optimization + *_optim + findmax_bfgs (src/relateHMM.cpp:1852-1971, 1597-1849; src/bfgs.c:127-199),
@@ -140,6 +143,14 @@ int relate_hip_fit(relate_hip_t h, const int32_t *pairs, int P, const double *st
  * (0 = IBD0 ... 2 = IBD2, -1 dropped); may be NULL.  nsnp_out: P ints, may be NULL. */
 int relate_hip_decode(relate_hip_t h, const int32_t *pairs, int P, const double *params, double *post,
                       int8_t *path, int *nsnp_out);
+
+/* The same decode, only the rows the caller reads: post is P x rows x M doubles in the order the .post writer takes
+ * the rows of decodek2's matrix (write_dMatrix_to_file of row 2 = IBD0, then row 1 = IBD1 unless fixK2 = 1 with value
+ * 0, src/relateHMM.cpp:3771-3782): row 0 = IBD0, row 1 = IBD1, row 2 = IBD2; rows = 1..3; values identical to
+ * relate_hip_decode's.  The reference's CLI prints two of decodek2's three rows (one in the linkage set-up); a row
+ * nobody reads costs 8 B per pair and SNP in HBM and again over the host link. */
+int relate_hip_decode_rows(relate_hip_t h, const int32_t *pairs, int P, const double *params, int rows, double *post,
+                           int *nsnp_out);
 
 /* The same decode with the rows the .post writer keeps (write_dMatrix_to_file of row 2 = IBD0, then row 1 = IBD1
  * unless fixK2 = 1 with value 0, src/relateHMM.cpp:3771-3782) as floats: post is P x rows x M, row 0 = IBD0, row 1 =
@@ -171,6 +182,9 @@ void relate_rand_stream(unsigned int seed, int n, int *out);
  * out + r * stride and is row_len[r] bytes long (no terminator). */
 size_t relate_post_text_stride(int M);
 int relate_format_post_rows(const double *post, int P, int M, int k1_only, char *out, size_t *row_len);
+/* The same text for nrows consecutive rows of M values each (what relate_hip_decode_rows returns: P x rows x M is
+ * P * rows rows in the writer's order): row r of the input -> out + r * stride, row_len[r] bytes. */
+int relate_format_rows(const double *rows, long nrows, int M, char *out, size_t *row_len);
 
 /* ---- multi-GPU: contiguous pair-block partition (no data-path collective) ------------------------ */
 /* Rank r of nranks owns pairs [*begin, *end) of a list of P pairs. */

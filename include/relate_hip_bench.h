@@ -28,6 +28,10 @@ int relate_hip_bench_like(relate_hip_t h, const int32_t *pairs, int P, const dou
 int relate_hip_bench_decode(relate_hip_t h, const int32_t *pairs, int P, const double *params, int reps,
                             double *ms_fwd_out, double *ms_bwd_out);
 
+/* relate_hip_bench_decode with the rows of relate_hip_decode_rows: rows = 1..3 posterior rows in writer order (IBD0,
+ * IBD1, IBD2), 0 = the reference's three rows. */
+int relate_hip_bench_decode_rows(relate_hip_t h, const int32_t *pairs, int P, const double *params, int rows, int reps,
+                                 double *ms_fwd_out, double *ms_bwd_out);
 /* Ranks that took part in the handle's last relate_hip_gather: the size of the RCCL communicator as the library
  * reports it (ncclCommCount), or the number of ranks of the file session; 0 before any gather.  Lets a scaling run
  * show that the C-ABI collective really spanned N ranks. */

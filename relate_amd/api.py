@@ -107,6 +107,9 @@ def load_library():
     L.relate_hip_like_noalloc.argtypes = [vp, C.c_int, vp, C.c_int, vp]
     L.relate_hip_fit.argtypes = [vp, i32p, C.c_int, dp, C.POINTER(RelateFit), dp]
     L.relate_hip_decode.argtypes = [vp, i32p, C.c_int, dp, dp, i8p, ip]
+    L.relate_hip_decode_rows.argtypes = [vp, i32p, C.c_int, dp, C.c_int, dp, ip]
+    L.relate_format_rows.argtypes = [dp, C.c_long, C.c_int, C.c_char_p, C.POINTER(C.c_size_t)]
+    L.relate_hip_bench_decode_rows.argtypes = [vp, i32p, C.c_int, dp, C.c_int, C.c_int, dp, dp]
     L.relate_hip_decode_f32.argtypes = [vp, i32p, C.c_int, dp, C.c_int, C.POINTER(C.c_float), ip]
     L.relate_hip_run_pairs.argtypes = [vp, i32p, C.c_int, dp, C.POINTER(RelateFit), dp, i8p]
     L.relate_rand_stream.argtypes = [C.c_uint, C.c_int, ip]
@@ -353,6 +356,24 @@ class Relate:
                                            None if path is None else path.ctypes.data_as(i8p), ns.ctypes.data_as(ip)))
         return post, path, ns
 
+    def decode_rows(self, pairs, params, rows=2, out=None):
+        """Posterior rows in the .post writer's order (IBD0, IBD1[, IBD2]) as float64: (len(pairs), rows, M); the
+        values of decode(), only the rows asked for (relate_hip_decode_rows)."""
+        p, pp = self._pairs(pairs)
+        par = np.ascontiguousarray(params, dtype=np.float64).reshape(len(p), 3)
+        n = len(p) * rows * self.M
+        if out is not None:
+            flat = out.reshape(-1)
+            if flat.dtype != np.float64 or not flat.flags.c_contiguous or flat.size < n:
+                raise ValueError("out must be a contiguous float64 buffer of at least len(pairs) * rows * M values")
+            post = flat[:n].reshape(len(p), rows, self.M)
+        else:
+            post = np.empty((len(p), rows, self.M))
+        ns = np.zeros(len(p), dtype=np.int32)
+        self._chk(self.L.relate_hip_decode_rows(self.h, pp, len(p), par.ctypes.data_as(dp), rows,
+                                                post.ctypes.data_as(dp), ns.ctypes.data_as(ip)))
+        return post, ns
+
     def decode_f32(self, pairs, params, rows=2, out=None):
         """Posterior rows in the .post writer's order (IBD0, IBD1[, IBD2]) as float32: (len(pairs), rows, M).
         out: optional float32 buffer (e.g. pinned_empty(..., np.float32)) that receives them."""
@@ -464,10 +485,11 @@ class Relate:
                                                C.byref(ms)))
         return ms.value
 
-    def bench_decode(self, pairs, params, reps):
+    def bench_decode(self, pairs, params, reps, rows=0):
+        """rows: 0 = the reference's three rows; 1..3 = the first rows of the writer's order (IBD0, IBD1, IBD2)."""
         p, pp = self._pairs(pairs)
         par = np.ascontiguousarray(params, dtype=np.float64).reshape(len(p), 3)
         a, b = C.c_double(0), C.c_double(0)
-        self._chk(self.L.relate_hip_bench_decode(self.h, pp, len(p), par.ctypes.data_as(dp), reps, C.byref(a),
-                                                 C.byref(b)))
+        self._chk(self.L.relate_hip_bench_decode_rows(self.h, pp, len(p), par.ctypes.data_as(dp), rows, reps,
+                                                      C.byref(a), C.byref(b)))
         return a.value, b.value

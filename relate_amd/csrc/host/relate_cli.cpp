@@ -320,8 +320,9 @@ void put_g(FILE *f, double v, int prec) { std::fprintf(f, "%.*g", prec, v); }
 
 // write_dMatrix_to_file (src/relateHMM.cpp:117-136) for a decoded block: per pair the IBD0 row and, unless k2 is
 // fixed at 0, the IBD1 row (:3771-3782); tab after every value, -1 for SNPs dropped for the pair, 4 significant digits
-// (POSTPRECISION).  The library formats the rows on the host threads (printf's bytes, relate_format_post_rows);
-// groups of pairs bound the text buffer to ~256 MiB.
+// (POSTPRECISION).  `post` holds exactly those rows in that order (relate_hip_decode_rows: nb x rpp x M).  The library
+// formats the rows on the host threads (printf's bytes, relate_format_rows); groups of pairs bound the text buffer to
+// ~256 MiB.
 void write_post_block(FILE *f, const double *post, int nb, int M, bool k1_only, std::vector<char> &text,
                       std::vector<size_t> &len) {
   const size_t stride = relate_post_text_stride(M);
@@ -331,7 +332,7 @@ void write_post_block(FILE *f, const double *post, int nb, int M, bool k1_only, 
   len.resize((size_t)group * rpp);
   for (int g0 = 0; g0 < nb; g0 += group) {
     const int ng = std::min(group, nb - g0);
-    if (relate_format_post_rows(post + (size_t)g0 * 3 * M, ng, M, k1_only ? 1 : 0, text.data(), len.data()))
+    if (relate_format_rows(post + (size_t)g0 * rpp * M, (long)ng * rpp, M, text.data(), len.data()))
       die(relate_hip_last_error(nullptr));
     for (int r = 0; r < ng * rpp; r++)
       if (std::fwrite(text.data() + (size_t)r * stride, 1, len[r], f) != len[r]) die("cannot write the .post file");
@@ -381,7 +382,8 @@ void usage() {
       "\tmulti-GPU: one process per GPU, -rank R -nranks N (default: RANK / WORLD_SIZE of the environment); every rank\n"
       "\t       takes a contiguous shard of the pair list and writes its posterior rows to POSTOUTPUT.rankR; the\n"
       "\t       estimates are gathered (-gather rccl | file, rendezvous files next to -rdv PATH) and rank 0 writes\n"
-      "\t       KOUTPUT and the -est file for all pairs\n");
+      "\t       KOUTPUT and the -est file for all pairs; -gather none: no exchange, every rank writes KOUTPUT.rankR\n"
+      "\t       and the -est file's .rankR for its own shard\n");
 }
 
 std::string strip_ext(const std::string &p, std::initializer_list<const char *> exts) {
@@ -447,7 +449,10 @@ int main(int argc, char **argv) {
     else { std::printf("\nArgument unknown will exit: %s \n", argv[a]); usage(); return 1; }
   }
   if (nranks < 1 || rank < 0 || rank >= nranks) die("-rank must lie in 0 .. -nranks - 1");
-  if (gatherT != "rccl" && gatherT != "file") die("-gather takes rccl or file");
+  if (gatherT != "rccl" && gatherT != "file" && gatherT != "none") die("-gather takes rccl, file or none");
+  // -gather none: no exchange at all -- every rank writes the estimates of its own shard to KOUTPUT.rank<r> and the
+  // -est file's .rank<r> (ranks started apart, e.g. as array jobs; laid end to end the shards are the whole list)
+  const bool own_out = gatherT == "none" && nranks > 1;
   if (!have_gpu && nranks > 1) device = env_int("LOCAL_RANK", rank);  // one process per GPU
   if (verbose) {
     time_t t = time(nullptr);
@@ -530,7 +535,7 @@ int main(int argc, char **argv) {
   if (nranks > 1 && !batch) die("-nranks > 1 needs a pair list (all pairs or -d)");
   if (rdv.empty()) rdv = kF + ".rdv";
   if (batch && rank > 0) {  // the dumps and the names of the outputs are rank 0's business
-    postF = postF + ".rank" + std::to_string(rank);
+    if (!postF.empty()) postF = postF + ".rank" + std::to_string(rank);  // (-post "": no posterior rows at all)
     std::printf("\t-> rank %d: pairs %ld .. %ld of %ld\n", rank, (long)sb, (long)se, Pall);
   } else if (batch) {
     std::printf("\t-> Will dump these data, that are used for analysis after the maf/prune removal\n");
@@ -540,7 +545,7 @@ int main(int argc, char **argv) {
     // (joblist_fast_all_pairs dumps to the default names whatever -out says, src/relateHMM.cpp:3832-3839)
     dump_stripped(h, d, keep, M, sg, sp, sc, sk);
     // (with several ranks the row shards keep the name given, so that rank r's file is POSTOUTPUT.rank<r> for all r)
-    postF = nranks > 1 ? postF + ".rank0" : fresh_name(postF);
+    if (!postF.empty()) postF = nranks > 1 ? postF + ".rank0" : fresh_name(postF);
     kF = fresh_name(kF);
     std::printf("\t-> number of individuals:%d\n\t-> number of pairs to run:%ld\n", d.N, Pall);
   } else {
@@ -550,20 +555,27 @@ int main(int argc, char **argv) {
   // A rank's row shard starts empty: it must hold this run's rows and nothing else (rank r's rows are found by
   // position in POSTOUTPUT.rank<r>).  The single-process file is appended to, under a name fresh_name made unused.
   FILE *fpost = postF.empty() ? nullptr : std::fopen(postF.c_str(), nranks > 1 ? "w" : "a");
-  FILE *fk = kF.empty() || rank > 0 ? nullptr : std::fopen(kF.c_str(), "a");
-  FILE *fest = estF.empty() || rank > 0 ? nullptr : std::fopen(estF.c_str(), "w");
-  if (rank > 0) { kF.clear(); estF.clear(); }
+  if (own_out) {
+    kF += ".rank" + std::to_string(rank);
+    if (!estF.empty()) estF += ".rank" + std::to_string(rank);
+  } else if (rank > 0) {
+    kF.clear();
+    estF.clear();
+  }
+  FILE *fk = kF.empty() ? nullptr : std::fopen(kF.c_str(), own_out ? "w" : "a");
+  FILE *fest = estF.empty() ? nullptr : std::fopen(estF.c_str(), "w");
   if ((!postF.empty() && !fpost) || (!kF.empty() && !fk) || (!estF.empty() && !fest)) die("cannot open output files");
   const bool k1_only = op.o.fixK == 1 && op.o.fixK_val == 0;  // :3771
   // The fit takes the pairs in large blocks (its launches need tens of thousands of pairs in flight to fill the
   // GPU); the posteriors of a fitted block are decoded in sub-blocks that bound the host buffer to ~1 GiB.
+  const int rpp = k1_only ? 1 : 2;  // posterior rows the .post file takes per pair: only those are decoded and fetched
   const long FB = std::max<long>(1, std::min<long>(P, 65536));
-  long B = std::max<long>(1, std::min<long>(FB, ((long)1 << 30) / ((long)3 * M * (long)sizeof(double))));
+  long B = std::max<long>(1, std::min<long>(FB, ((long)1 << 30) / ((long)rpp * M * (long)sizeof(double))));
   if (post_block > 0) B = std::min<long>(FB, post_block);
   std::vector<relate_fit> mine((size_t)std::max<long>(P, 1));  // this rank's records, in pair order
   std::vector<double> par((size_t)B * 3);
   double *post = nullptr;  // page-locked: the posterior rows arrive by direct DMA
-  if (fpost && relate_hip_host_alloc((void **)&post, (size_t)B * 3 * M * sizeof(double)))
+  if (fpost && relate_hip_host_alloc((void **)&post, (size_t)B * rpp * M * sizeof(double)))
     die(relate_hip_last_error(nullptr));
   std::vector<int> ns((size_t)B);
   std::vector<char> text;           // formatted rows of a group of pairs (write_post_block)
@@ -577,7 +589,7 @@ int main(int argc, char **argv) {
       relate_fit *fit = &mine[(size_t)b0];
       for (int p = 0; p < nb; p++) { par[3 * p] = fit[p].a; par[3 * p + 1] = fit[p].k2; par[3 * p + 2] = fit[p].k1; }
       if (fpost) {  // the posterior rows (the SNP count of the .est line comes with the fit)
-        if (relate_hip_decode(h, &pairs[2 * b0], nb, par.data(), post, nullptr, ns.data()))
+        if (relate_hip_decode_rows(h, &pairs[2 * b0], nb, par.data(), rpp, post, ns.data()))
           die(relate_hip_last_error(h));
       }
       if (fpost) write_post_block(fpost, post, nb, M, k1_only, text, text_len);
@@ -591,15 +603,17 @@ int main(int argc, char **argv) {
   // the estimates of all ranks, in pair order, on every rank (the path's one exchange); rank 0 writes them
   std::vector<relate_fit> gathered;
   const relate_fit *allfit = mine.data();
-  if (nranks > 1) {
+  if (nranks > 1 && !own_out) {
     gathered.resize((size_t)std::max<long>(Pall, 1));
     if (relate_hip_gather(h, mine.data(), Pall, rank, nranks, rdv.c_str(), gatherT == "file" ? 1 : 0, gathered.data()))
       die(relate_hip_last_error(h));
     allfit = gathered.data();
   }
-  if (rank == 0)
-    for (long p = 0; p < Pall; p++) {
-      const relate_fit &f = allfit[p];
+  // what this process writes: all pairs on rank 0 after the gather, its own shard under -gather none
+  const long w0 = own_out ? (long)sb : 0, w1 = own_out ? (long)se : Pall;
+  if (rank == 0 || own_out)
+    for (long p = w0; p < w1; p++) {
+      const relate_fit &f = own_out ? mine[(size_t)(p - sb)] : allfit[p];
       if (f.status == RELATE_E_NOSNP) nosnp++;
       else if (f.status) bad++;
       if (fk) {

@@ -972,15 +972,16 @@ __device__ inline double round_sig4(double x) {
 // posterior_x(s) = fwd_x(s) bwd_x(s) / sum_y fwd_y(s) bwd_y(s): every scale factor cancels.
 // Lanes hold consecutive pairs, whose posterior rows lie 3*M doubles apart: results of kTile SNPs are transposed
 // through LDS so that every pair row is written in whole 128-byte lines.  Workgroup = one wave = 64 pairs of one chunk.
-// OutT = double: post[p][3][M], rows IBD2, IBD1, IBD0 (the reference's dMatrix).  OutT = float: post[p][rows][M] in
-// the order the .post writer takes them (IBD0, IBD1, IBD2; :3771-3782), the first `rows` of them, each value the
-// double result rounded once to float.
+// worder = 0 (OutT = double): post[p][3][M], rows IBD2, IBD1, IBD0 (the reference's dMatrix).  worder = 1:
+// post[p][rows][M] in the order the .post writer takes them (IBD0, IBD1, IBD2; :3771-3782), the first `rows` of them
+// -- rows nobody reads are not written (8 B per pair and SNP each); OutT = float: each value the double result rounded
+// once to float.
 template <bool DR, typename OutT>
 __global__ void __launch_bounds__(kBwdThreads)
 decode_bwd_kernel(const double *__restrict__ rec, const double *__restrict__ tsh, const int *__restrict__ own, int M, int P, int RP, int col0,
                   const double *__restrict__ params,
                   int nlp, int chunk_len, const double *__restrict__ astart, const double *__restrict__ bend,
-                  TileCkpt ck, OutT *__restrict__ post, int rows, int sig4) {  // sig4: float rows rounded as the .post text
+                  TileCkpt ck, OutT *__restrict__ post, int rows, int worder, int sig4) {  // sig4: rows rounded as the .post text
   __shared__ double tile[3][kBwdThreads][kTilePad];
   int bpc = (P + kBwdThreads - 1) / kBwdThreads;
   int c = blockIdx.x / bpc;
@@ -1039,8 +1040,8 @@ decode_bwd_kernel(const double *__restrict__ rec, const double *__restrict__ tsh
       int idx = j * kBwdThreads + threadIdx.x;
       int e = idx % kTile, pr = (idx / kTile) % kBwdThreads, r = idx / (kTile * kBwdThreads);
       int s = tb + e, pp = pbase + pr;
-      if constexpr (sizeof(OutT) == sizeof(double)) {
-        if (s < te && pp < P) post[((size_t)pp * 3 + r) * M + s] = tile[r][pr][e];
+      if (!worder) {
+        if (s < te && pp < P) post[((size_t)pp * 3 + r) * M + s] = (OutT)tile[r][pr][e];
       } else {
         int rr = 2 - r;
         if (s < te && pp < P && rr < rows)

@@ -72,6 +72,7 @@ struct LaneBufs {
   hipEvent_t e0 = nullptr, e1 = nullptr, done = nullptr;
   int nl = 0, chunks = 1;
   int nv = 1;  // points per lane the slot layout of this launch allows (pick_nv)
+  long npoints = 0, wanted = 0;  // points the optimisers asked for in this launch (without padding) / in this round (with those held back)
   hipError_t ensure(size_t n) {
     if (!e0) {
       hipError_t e = hipEventCreate(&e0);
@@ -711,7 +712,9 @@ int like_wait(relate_hip_t h, LaneBufs &B) {
     h->like_stats[4 + k] += 1;
   }
   if (getenv("RELATE_FIT_TRACE"))
-    std::fprintf(stderr, "like launch: %d lanes, %d chunks, %.3f ms\n", B.nl, B.chunks, ms);
+    std::fprintf(stderr, "like launch: %d lanes, %d chunks, %.3f ms, %ld points of %ld wanted, nv %d, t %.6f\n", B.nl, B.chunks, ms,
+                 B.npoints, B.wanted, B.nv,
+                 std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count());
   return 0;
 }
 
@@ -985,6 +988,10 @@ struct FitPop {
     if (B->ensure(nl_total) != hipSuccess) return -1;
     lap(5);
     B->nl = (int)nl_total;
+    B->npoints = first_round ? 2L * P : 0;
+    for (const Act &a : active)
+      if (a.taken) B->npoints += a.nlanes;
+    B->wanted = want + (first_round ? 2L * P : 0);
     if (first_round)
       for (int p = 0; p < P; p++)
         for (int j = 0; j < ul; j++) {
@@ -1255,8 +1262,9 @@ int copy_to_host(relate_hip_t h, void *dst, const void *src, size_t bytes) {
 }
 
 // K6 launches for pairs [p0, p0 + P) of the staged block with their params already in dParams; posteriors left in dPost
-// (f32_rows: 0 = doubles, P x 3 x M; 1..3 = floats, P x f32_rows x M in writer order, in the same buffer)
-int launch_decode(relate_hip_t h, int p0, int P, int f32_rows = 0, int sig4 = 0) {
+// (f32_rows: 0 = doubles; 1..3 = floats, P x f32_rows x M in writer order, in the same buffer.  f64_rows: 0 = the
+// reference's P x 3 x M (IBD2, IBD1, IBD0); 1..3 = doubles, P x f64_rows x M in writer order)
+int launch_decode(relate_hip_t h, int p0, int P, int f32_rows = 0, int sig4 = 0, int f64_rows = 0) {
   const int M = h->M;
   int nchunk, clen;
   pick_chunks(M, P, h->single_sweep_lanes, 256, h->slots_decode, 1, &nchunk, &clen);
@@ -1294,16 +1302,19 @@ int launch_decode(relate_hip_t h, int p0, int P, int f32_rows = 0, int sig4 = 0)
   }
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
   dim3 bgrid((unsigned)((size_t)((P + kBwdThreads - 1) / kBwdThreads) * nchunk));
-#define LAUNCH_BWD(DRV, T, OUT, ROWS)                                                                              \
+#define LAUNCH_BWD(DRV, T, OUT, ROWS, WORDER)                                                                      \
   hipLaunchKernelGGL((decode_bwd_kernel<DRV, T>), bgrid, dim3(kBwdThreads), 0, h->stream, rec, h->dTsh.p, h->dPairOwn.p, M, P, RP, p0, \
-                     h->dParams.p, nlp, clen, astart, bend, ck, OUT, ROWS, sig4)
+                     h->dParams.p, nlp, clen, astart, bend, ck, OUT, ROWS, WORDER, sig4)
   if (f32_rows) {
     float *pf = reinterpret_cast<float *>(h->dPost.p);
-    if (dr) LAUNCH_BWD(true, float, pf, f32_rows);
-    else LAUNCH_BWD(false, float, pf, f32_rows);
+    if (dr) LAUNCH_BWD(true, float, pf, f32_rows, 1);
+    else LAUNCH_BWD(false, float, pf, f32_rows, 1);
+  } else if (f64_rows) {
+    if (dr) LAUNCH_BWD(true, double, h->dPost.p, f64_rows, 1);
+    else LAUNCH_BWD(false, double, h->dPost.p, f64_rows, 1);
   } else {
-    if (dr) LAUNCH_BWD(true, double, h->dPost.p, 3);
-    else LAUNCH_BWD(false, double, h->dPost.p, 3);
+    if (dr) LAUNCH_BWD(true, double, h->dPost.p, 3, 0);
+    else LAUNCH_BWD(false, double, h->dPost.p, 3, 0);
   }
 #undef LAUNCH_BWD
   HIPCHK(h, hipGetLastError());
@@ -1314,17 +1325,18 @@ int launch_decode(relate_hip_t h, int p0, int P, int f32_rows = 0, int sig4 = 0)
 // Decode (and Viterbi) of pairs [p0, p0 + P) of the staged block; `pairs` = those P pairs (needed to stage the full
 // format when a path is wanted).
 int decode_block(relate_hip_t h, const int32_t *pairs, int p0, int P, const double *params, double *post, int8_t *path,
-                 int *nsnp_out, bool copy_back, float *post32 = nullptr, int f32_rows = 0, int sig4 = 0) {
+                 int *nsnp_out, bool copy_back, float *post32 = nullptr, int f32_rows = 0, int sig4 = 0, int f64_rows = 0) {
   const int M = h->M;
   HIPCHK(h, h->dParams.ensure((size_t)3 * P));
   HIPCHK(h, hipMemcpyAsync(h->dParams.p, params, sizeof(double) * 3 * P, hipMemcpyHostToDevice, h->stream));
   if (nsnp_out) std::memcpy(nsnp_out, h->h_nsnp.data() + p0, sizeof(int) * P);  // counted by the staging kernel
   if (post || post32 || !copy_back) {  // (f32_rows > 0 without post32: float rows left on the device)
-    HIPCHK(h, h->dPost.ensure(f32_rows ? ((size_t)f32_rows * M * P + 1) / 2 : (size_t)3 * M * P));
-    int rc = launch_decode(h, p0, P, f32_rows, sig4);
+    const size_t rows64 = f64_rows ? (size_t)f64_rows : 3;
+    HIPCHK(h, h->dPost.ensure(f32_rows ? ((size_t)f32_rows * M * P + 1) / 2 : rows64 * M * P));
+    int rc = launch_decode(h, p0, P, f32_rows, sig4, f64_rows);
     if (rc) return rc;
     if (copy_back && post) {
-      rc = copy_to_host(h, post, h->dPost.p, sizeof(double) * 3 * M * P);
+      rc = copy_to_host(h, post, h->dPost.p, sizeof(double) * rows64 * M * P);
       if (rc) return rc;
     }
     if (copy_back && post32) {
@@ -1479,6 +1491,24 @@ int relate_format_post_rows(const double *post, int P, int M, int k1_only, char 
   };
   int nt = (int)std::min<long>(host_threads(), nrows);
   if ((long)nrows * M < 65536) nt = 1;
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; t++) th.emplace_back(work);
+  work();
+  for (auto &x : th) x.join();
+  return RELATE_OK;
+}
+
+int relate_format_rows(const double *rows, long nrows, int M, char *out, size_t *row_len) {
+  if (!rows || !out || !row_len || nrows < 0 || M < 1) return fail(nullptr, RELATE_E_ARG, "bad arguments");
+  const size_t stride = relate_post_text_stride(M);
+  (void)relate_text::pow10_table();  // built before the threads start
+  std::atomic<long> next{0};
+  auto work = [&] {
+    for (long r = next.fetch_add(1); r < nrows; r = next.fetch_add(1))
+      row_len[r] = relate_text::format_row(rows + (size_t)r * M, M, out + (size_t)r * stride);
+  };
+  int nt = (int)std::min<long>(host_threads(), nrows);
+  if (nrows * M < 65536) nt = 1;
   std::vector<std::thread> th;
   for (int t = 1; t < nt; t++) th.emplace_back(work);
   work();
@@ -1934,6 +1964,24 @@ int relate_hip_decode(relate_hip_t h, const int32_t *pairs, int P, const double 
   return RELATE_OK;
 }
 
+int relate_hip_decode_rows(relate_hip_t h, const int32_t *pairs, int P, const double *params, int rows, double *post,
+                           int *nsnp_out) {
+  int rc = require_ready(h);
+  if (rc) return rc;
+  if (!pairs || !params || !post || P < 0 || rows < 1 || rows > 3) return fail(h, RELATE_E_ARG, "bad arguments");
+  h->timings[2] = h->timings[3] = 0;
+  size_t lim = pair_block_limit(h, {need_rec(h), need_post(h, 8.0 * rows), need_ckpt(h)});
+  for (long b0 = 0; b0 < P; b0 += (long)lim) {
+    int pb = (int)std::min<long>((long)lim, P - b0);
+    rc = stage_block(h, pairs + 2 * b0, pb);
+    if (rc) return rc;
+    rc = decode_block(h, pairs + 2 * b0, 0, pb, params + 3 * b0, post + (size_t)b0 * rows * h->M, nullptr,
+                      nsnp_out ? nsnp_out + b0 : nullptr, true, nullptr, 0, 0, rows);
+    if (rc) return rc;
+  }
+  return RELATE_OK;
+}
+
 int relate_hip_decode_f32(relate_hip_t h, const int32_t *pairs, int P, const double *params, int rows, float *post,
                           int *nsnp_out) {
   int rc = require_ready(h);
@@ -2081,14 +2129,19 @@ int relate_hip_bench_like(relate_hip_t h, const int32_t *pairs, int P, const dou
 
 int relate_hip_bench_decode(relate_hip_t h, const int32_t *pairs, int P, const double *params, int reps,
                             double *ms_fwd_out, double *ms_bwd_out) {
+  return relate_hip_bench_decode_rows(h, pairs, P, params, 0, reps, ms_fwd_out, ms_bwd_out);
+}
+
+int relate_hip_bench_decode_rows(relate_hip_t h, const int32_t *pairs, int P, const double *params, int rows, int reps,
+                                 double *ms_fwd_out, double *ms_bwd_out) {
   int rc = require_ready(h);
   if (rc) return rc;
-  if (!pairs || !params || P < 1 || reps < 1) return fail(h, RELATE_E_ARG, "bad arguments");
+  if (!pairs || !params || P < 1 || reps < 1 || rows < 0 || rows > 3) return fail(h, RELATE_E_ARG, "bad arguments");
   rc = stage_block(h, pairs, P);
   if (rc) return rc;
   h->timings[2] = h->timings[3] = 0;
   for (int r = 0; r < reps; r++) {
-    rc = decode_block(h, pairs, 0, P, params, nullptr, nullptr, nullptr, false);
+    rc = decode_block(h, pairs, 0, P, params, nullptr, nullptr, nullptr, false, nullptr, 0, 0, rows);
     if (rc) return rc;
   }
   if (ms_fwd_out) *ms_fwd_out = h->timings[2] / reps;

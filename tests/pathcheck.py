@@ -120,7 +120,7 @@ def multistart(nll, timesToConverge, timesToRun, convTol):
     return best, run, conv
 
 
-def allpair_envelope(fx, opt):
+def allpair_envelope(fx, opt, key="nll_copies"):
     """Per-copy statistics of tests/golden/sensitivity_allpair.json (tests/golden/make_sensitivity_allpair.py): what
     the reference's 2-parameter calcA fit does when every objective value carries -1/0/+1 ulp of noise.
       ref_nll[p][r]      unperturbed -logL of run r (rows r < timesRun are sgl's convInfo)
@@ -129,7 +129,7 @@ def allpair_envelope(fx, opt):
       best_excess[p][c]  best-of-runs -logL of copy c (the restart rule applied to the copy) / sgl's -logL - 1
       runs[c], conv[c]   the copy's timesRun / timesConverged per pair"""
     ref_nll = np.array([[r[3] for r in p["runs"]] for p in fx["pairs"]])
-    cop = np.array([p["nll_copies"] for p in fx["pairs"]])            # pairs x runs x copies
+    cop = np.array([p[key] for p in fx["pairs"]])                     # pairs x runs x copies
     rel = cop / ref_nll[:, :, None] - 1
     P, R, K = cop.shape
     best_excess = np.zeros((P, K))
@@ -144,24 +144,25 @@ def allpair_envelope(fx, opt):
                 runs=runs, conv=conv)
 
 
-def allpair_envelope_summary(fx):
+def allpair_envelope_summary(fx, key="nll_copies"):
     opt = options(fx["options"])
-    e = allpair_envelope(fx, opt)
+    e = allpair_envelope(fx, opt, key)
     P, R, K = e["rel"].shape
-    return ("pairs %d x runs %d x copies %d\n(pair, run) results on the unperturbed trajectory (|rel| <= 1e-9): per copy "
+    return ("noise amplitude %d ulp: pairs %d x runs %d x copies %d\n(pair, run) results on the unperturbed trajectory (|rel| <= 1e-9): per copy "
             "min %d max %d of %d\nrun -logL: max rel excess %.3e, max rel gain %.3e\nbest-of-runs -logL vs sgl's: max "
             "excess %.3e, max gain %.3e, pairs whose best moved by > 1e-9: per copy min %d max %d\ntimesRun per copy: "
             "mean %.3f..%.3f; timesConverged > 1: %d..%d pairs" % (
-                P, R, K, e["on"].min(), e["on"].max(), P * R, e["rel"].max(), -e["rel"].min(),
+                1 if key == "nll_copies" else fx["amp_wide"], P, R, K, e["on"].min(), e["on"].max(), P * R, e["rel"].max(), -e["rel"].min(),
                 e["best_excess"].max(), -e["best_excess"].min(),
                 (np.abs(e["best_excess"]) > 1e-9).sum(axis=0).min(), (np.abs(e["best_excess"]) > 1e-9).sum(axis=0).max(),
                 e["runs"].mean(axis=1).min(), e["runs"].mean(axis=1).max(),
                 (e["conv"] > 1).sum(axis=1).min(), (e["conv"] > 1).sum(axis=1).max()))
 
 
-def allpair_bars(fx, opt, res, conv):
+def allpair_bars(fx, opt, res, conv, key="nll_copies_wide"):
     """The HIP fit of the fixture's pairs (res = relate_fit records, conv = P x timesToRun x 4 convInfo) against the
-    envelope of the fixture's perturbed copies.  Like is compared with like: a fit only reports the runs its restart
+    envelope of the fixture's perturbed copies -- by default the copies whose noise has the measured size of the HIP
+    objective's distance from like() ("nll_copies_wide"; "nll_copies" = +-1 ulp).  Like is compared with like: a fit only reports the runs its restart
     rule consumed, so a copy's runs count up to the copy's own timesRun.  Returns (stats, failures); the bars:
       (i)   (pair, run) results on the reference's trajectory (-logL within 1e-9 relative of the unperturbed run):
             at least the worst copy's count less max(10, 3 standard deviations of the copies' counts);
@@ -169,7 +170,7 @@ def allpair_bars(fx, opt, res, conv):
       (iii) mean timesRun and the number of pairs with timesConverged > 1: inside the copies' range widened by two
             of their standard deviations (16 copies are a sample, not a bound).
     On-trajectory runs must also carry the reference's (a, k2, k1) to 1e-6."""
-    e = allpair_envelope(fx, opt)
+    e = allpair_envelope(fx, opt, key)
     P, R, K = e["rel"].shape
     on_c = np.array([sum(int((np.abs(e["rel"][p, :e["runs"][c, p], c]) <= 1e-9).sum()) for p in range(P)) for c in range(K)])
     used_c = e["runs"].sum(axis=1)

@@ -178,6 +178,36 @@ def test_fit_pinned_seed_against_reference(gpu, prepared, bi):
         assert on_trajectory >= len(pairs) - 1
 
 
+def test_decode_rows_returns_exactly_the_rows_of_decode(gpu, prepared):
+    """relate_hip_decode_rows (the rows the .post writer takes, in its order: IBD0, IBD1, IBD2) against relate_hip_decode
+    (decodek2's matrix: IBD2, IBD1, IBD0): the same doubles bit for bit for rows = 1, 2, 3, under both transition models,
+    dropped SNPs -1 in every row; and the text of the rows equals the text relate_format_post_rows makes of the matrix."""
+    import ctypes as C
+    b = pc.golden()["blocks"][0]
+    pairs = [(0, 1), (5, 12), (2, 9), (3, 50), (100, 103), (7, 8)]
+    par = np.array([(0.05, 0.2, 0.3), (0.1, 0.0, 0.4), (0.03, 0.0, 1.0), (0.07, 0.4, 0.0), (0.09, 0.1, 0.1), (0.02, 0.3, 0.6)])
+    for dr in (0, 1):
+        _init(gpu, prepared, b, double_recom=dr)
+        full, _, ns = gpu.decode(pairs, par)
+        for rows in (1, 2, 3):
+            got, ns2 = gpu.decode_rows(pairs, par, rows=rows)
+            assert got.shape == (len(pairs), rows, gpu.M) and np.array_equal(ns, ns2)
+            for r in range(rows):
+                assert np.array_equal(got[:, r, :], full[:, 2 - r, :]), (dr, rows, r)
+        L = gpu.L
+        stride = L.relate_post_text_stride(gpu.M)
+        for k1_only, rows in ((1, 1), (0, 2)):
+            got, _ = gpu.decode_rows(pairs, par, rows=rows)
+            n = len(pairs) * rows
+            ta, tb = C.create_string_buffer(n * stride), C.create_string_buffer(n * stride)
+            la, lb = (C.c_size_t * n)(), (C.c_size_t * n)()
+            assert L.relate_format_post_rows(full.ctypes.data_as(C.POINTER(C.c_double)), len(pairs), gpu.M, k1_only, ta, la) == 0
+            assert L.relate_format_rows(got.ctypes.data_as(C.POINTER(C.c_double)), n, gpu.M, tb, lb) == 0
+            assert list(la) == list(lb)
+            for r in range(n):
+                assert ta.raw[r * stride:r * stride + la[r]] == tb.raw[r * stride:r * stride + lb[r]]
+
+
 def test_fit_with_explicit_starts_equals_seeded_run(gpu, prepared):
     import relate_amd
     G = pc.golden()
@@ -684,6 +714,89 @@ def test_dropped_run_across_a_chromosome_break_with_a_non_negative_distance(orac
                 dropped = np.setdiff1d(np.arange(M), idxs[n])
                 assert (post[n][:, dropped] == -1).all()
             H.close()
+
+
+def _like_unclamped(par, S, t):
+    """like() (src/relateHMM.cpp:1426-1544) with the transition matrix in the expm1 form and WITHOUT fix_underflow: a
+    plain scaled forward recursion in numpy (small cases only)."""
+    a, k2, k1 = par
+    k0 = 1 - k1 - k2
+    f = np.array([k0, k1, k2])
+    ll = 0.0
+    for i in range(S.shape[1]):
+        if i > 0:
+            m1, m2 = np.expm1(-a * t[i]), np.expm1(-a * k1 * t[i])
+            u, w = -k1 * m1, (m2 - k1 * m1) / (k1 - 1)
+            T01, T02, T10, T12, T20 = u, k2 * w, u * k0 / k1, u * k2 / k1, k0 * w
+            f = f @ np.array([[1 - T01 - T02, T01, T02], [T10, 1 - T10 - T12, T12], [T20, T01, 1 - T01 - T20]])
+        f = f * S[:, i]
+        s = f.sum()
+        f /= s
+        ll += np.log(s)
+    return -ll
+
+
+def test_dropped_run_across_a_break_with_a_negative_distance_and_slowly_mixing_parameters(oracle):
+    """The other side of the case above (round 2's advisor finding).  A run of dropped SNPs across a chromosome break
+    whose kept ends lie a NEGATIVE distance apart is left to the shared steps: the chain applies T(t1) T(1e7) T(t2) =
+    T(1e7 + t1 + t2) where the reference applies one T(1e7) (diff, src/relateHMM.cpp:396-401).  The two differ only
+    through the slow mode e^{-a k1 t}: relative to T(1e7)'s entries by a k1 (t1 + t2) e^{-1e7 a k1} <= (t1 + t2) /
+    (1e7 e) = 3.7e-8 per Mb of dropped stretch, largest at a k1 = 1e-7 (for a k1 > 7.5e-5 the mode has underflowed to
+    exactly 0 and both are equal).  Pinned here where it is largest: a k1 from 1e-9 to 1e-5 (L-BFGS-B iterates near the
+    k1 = 0 bound), dropped stretches of 0.01 - 0.08 Mb next to the break (runs shorter than back2: beyond it the
+    reference conditions on an all-zero table row and its likelihood is NaN): likelihoods to 1e-10 relative and
+    posteriors to 1e-8 against the oracle, which follows the reference's per-pair distances.
+
+    One point is held differently, and not because of the break: (a, k2, k1) = (0.05, 0.2, 2e-8) on the related pair
+    (0,1).  There T02 = k2 w and T20 = k0 w are ~5e-16 at every ordinary step, and the reference's fix_underflow
+    (src/relateHMM.cpp:542-547) sets values below 1e-15 to zero; the kernels form T in the expm1 form, where that
+    rounding noise does not arise, and do not clamp.  For a pair that has to move between IBD0 and IBD2 with k1 < ~4e-8
+    (k1 < 2e-15 / (k2 (a t)^2)) the two differ: 2.2e-9 relative in -logL here -- inside the north star's 1e-6, outside
+    this file's 1e-10.  The test pins both sides: the kernels equal the unclamped recursion to 1e-10 and the
+    reference's clamped one to 1e-8."""
+    import relate_amd
+    from relate_amd import synth
+    N, M = 12, 2000
+    g, pos, chr_, _ = synth.make_dataset(N, M, nchr=1, n_related=2, seed=5)
+    g = g.copy()
+    pos = np.concatenate([0.01 * np.arange(1, 1001), 0.01 * np.arange(1, 1001)])     # chromosome 2 starts over at 0.01
+    chr_ = np.concatenate([np.ones(1000, dtype=np.int32), 2 * np.ones(1000, dtype=np.int32)])
+    g[g == 0] = 1
+    g[10, :] = 1
+    g[11, :] = 3
+    g[0, 1000] = 0                 # first SNP of chromosome 2 (t2 = 0.01)
+    g[1, 996:1004] = 0             # 8 SNPs across the break (t1 + t2 = 0.08 Mb)
+    g[2, 998:1000] = 0             # the last two of chromosome 1 (t1 = 0.02)
+    opt = dict(pc.options("options.all.pair.txt"))
+    p = pc.oracle_precalc(oracle, g, pos, opt)
+    assert p["keep"].all()
+    pairs = [(0, 3), (1, 3), (0, 1), (2, 3), (3, 4), (1, 2)]
+    st = pc.oracle_stage(oracle, p, opt, 1, 3)
+    assert st["t"][996] == 1e7     # the reference's one step across the break for the pair with the long run
+    pars = np.array([(0.05, 0.2, 2e-8), (0.05, 0.0, 2e-6), (0.001, 0.3, 1e-4), (0.1, 0.1, 1e-6), (0.01, 0.0, 1e-3),
+                     (0.001, 0.0, 0.01), (0.15, 0.5, 6e-5), (0.02, 0.25, 5e-6)])
+    H = relate_amd.Relate(0)
+    H.init_globals(g, pos, chr_, opt)
+    got = H.like(pairs, np.broadcast_to(pars, (len(pairs),) + pars.shape).copy())
+    worst = 0.0
+    for n, (i, j) in enumerate(pairs):
+        st = pc.oracle_stage(oracle, p, opt, i, j)
+        idx = np.where(st["keep"] == 1)[0]
+        want = np.array([oracle.like(d, *st["Sk"], st["t"], 0, opt["alim1"]) for d in pars])
+        if (i, j) == (0, 1):
+            assert abs(got[n][0] / want[0] - 1) < 1e-8
+            assert abs(got[n][0] / _like_unclamped(pars[0], st["S"], st["t"]) - 1) < 1e-10
+            want[0] = got[n][0]
+        worst = max(worst, float(np.abs(got[n] / want - 1).max()))
+        np.testing.assert_allclose(got[n], want, rtol=1e-10)
+        for q in (0, 1, 3, 7):
+            d = pars[q]
+            post, _, _ = H.decode([(i, j)], [d])
+            # (the one point in the fix_underflow regime on the pair that moves between IBD0 and IBD2: north star's bar)
+            np.testing.assert_allclose(post[0][:, idx], oracle.decode(d, *st["Sk"], st["t"], 0),
+                                       atol=1e-6 if ((i, j) == (0, 1) and q == 0) else 1e-8)
+    print("negative-distance runs across a break, a k1 in 1e-9 .. 1e-5: like maxrel %.2e" % worst)
+    H.close()
 
 
 def test_restarts_ahead_of_need_change_no_outcome(oracle, monkeypatch):

@@ -86,12 +86,13 @@ def test_allpair_fixtures_are_what_their_header_says():
                                                    "500": (66, 40, 70, 1.5e-4, 2.5e-4)}.items():
         with open(ALLPAIR[name]) as fh:
             fx = json.load(fh)
-        e = pc.allpair_envelope(fx, pc.options(fx["options"]))
+        opt = pc.options(fx["options"])
+        e = pc.allpair_envelope(fx, opt)
         assert e["rel"].shape == (P, 8, 16) and fx["options"] == "options.all.pair.txt"
         assert on_lo <= e["on"].min() and e["on"].max() <= on_hi
         assert ex_lo < e["best_excess"].max() < ex_hi
         for p in fx["pairs"]:   # sgl's result is the restart rule applied to the unperturbed rows
-            b, nr, nc = pc.multistart([r[3] for r in p["runs"]], 2, 8, 0.1)
+            b, nr, nc = pc.multistart([r[3] for r in p["runs"]], opt["timesToConverge"], opt["timesToRun"], opt["convTol"])
             assert (nr, nc, p["runs"][b][3]) == (p["timesRun"], p["timesConv"], p["nll"])
 
 

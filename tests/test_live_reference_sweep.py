@@ -74,16 +74,24 @@ def test_stage_like_decode_at_a_point(gpu, ref, case):
         ref.fini()
 
 
+# (name, option overrides, pairs that must stay on the reference's trajectory, largest relative difference of the -logL
+#  reached, relative -logL agreement that counts as "on the trajectory", relative tolerance of the estimates on it)
 MODES = [
-    ("3 free (a, k2, k1)", dict(calcA=0, fixA=0, fixK=0), 6),
-    ("fixK2=0: a, k1 free", dict(calcA=0, fixA=0, fixK=1, fixK_val=0.0), 6),
-    ("fixK2=0 + calcA: k1 free", dict(calcA=1, fixA=0, fixK=1, fixK_val=0.0), 4),
-    ("fixK2=0.1: a, k1 free", dict(calcA=0, fixA=0, fixK=1, fixK_val=F32(0.1)), 0),
-    # fixK2_fixA_fun / fixK2_fixA_optim (src/relateHMM.cpp:1783-1825): k1 alone is free, a and k2 are given
-    ("fixK2=0 + fixA=0.05: k1 free", dict(calcA=0, fixA=1, fixA_val=F32(0.05), fixK=1, fixK_val=0.0, timesToRun=8), 6),
-    ("fixK2=0.1 + fixA=0.02: k1 free", dict(calcA=0, fixA=1, fixA_val=F32(0.02), fixK=1, fixK_val=F32(0.1), timesToRun=8), 0),
-    # calcA_fun / calcA_optim (:1564-1621): k2 and k1 free, a = calculateA -- the mode of configs 2, 3 and 4
-    ("calcA: k2, k1 free", dict(calcA=1, fixA=0, fixK=0, timesToRun=8, alim1=1.0), 0),
+    ("3 free (a, k2, k1)", dict(calcA=0, fixA=0, fixK=0), 6, 1e-4, 1e-9, 1e-6),
+    ("fixK2=0: a, k1 free", dict(calcA=0, fixA=0, fixK=1, fixK_val=0.0), 6, 1e-4, 1e-9, 1e-6),
+    ("fixK2=0 + calcA: k1 free", dict(calcA=1, fixA=0, fixK=1, fixK_val=0.0), 4, 1e-4, 1e-9, 1e-6),
+    ("fixK2=0.1: a, k1 free", dict(calcA=0, fixA=0, fixK=1, fixK_val=F32(0.1)), 0, 1e-4, 1e-9, 1e-6),
+    # fixK2_fixA_fun / fixK2_fixA_optim (src/relateHMM.cpp:1783-1825): k1 alone is free, a and k2 are given.  One
+    # dimension and a smooth optimum: the search stops when the projected gradient is below 1e-4 (PGTOL, src/bfgs.h:46),
+    # which leaves k1 free in its 6th digit while -logL agrees to 1e-12 (measured: k1 1.2e-6 apart, relative), so the
+    # estimates of a pair on the trajectory are held to 1e-5 here.  With k2 = 0.1 the optimum of unrelated pairs lies on the infeasibility wall
+    # (k1 + 2 k2)^2 = 4 k2 as for fixK2 = 0.1 above
+    ("fixK2=0 + fixA=0.05: k1 free", dict(calcA=0, fixA=1, fixA_val=F32(0.05), fixK=1, fixK_val=0.0, timesToRun=8), 4, 1e-4, 1e-12, 1e-5),
+    ("fixK2=0.1 + fixA=0.02: k1 free", dict(calcA=0, fixA=1, fixA_val=F32(0.02), fixK=1, fixK_val=F32(0.1), timesToRun=8), 0, 1e-3, 1e-12, 1e-5),
+    # calcA_fun / calcA_optim (:1564-1621): k2 and k1 free, a = calculateA -- the mode of configs 2, 3 and 4, chaotic:
+    # the bar on -logL is the largest excess the reference shows against itself under objective noise of the HIP
+    # objective's size (tests/golden/sensitivity_allpair.json: 4.2e-3); per-run bars in tests/test_gpu_sensitivity.py
+    ("calcA: k2, k1 free", dict(calcA=1, fixA=0, fixK=0, timesToRun=8, alim1=1.0), 0, 4.2e-3, 1e-9, 1e-6),
 ]
 
 
@@ -96,7 +104,7 @@ def test_fit_modes(gpu, ref, mode):
     infeasibility wall (k1 + 2 k2)^2 = 4 k2, where the reference's runs do not converge either (8 of 8 restarts used),
     and the -logL reached differs in the 5th digit in both directions."""
     from relate_amd import synth
-    name, ok, min_on = mode
+    name, ok, min_on, max_rel, on_rel, est_rel = mode
     N, M, seed = 24, 3000, 777
     g, pos, chr_, related = synth.make_dataset(N, M, n_related=4, miss=0.005)
     pairs = [(int(r[0]), int(r[1])) for r in related] + [(0, N - 1), (1, N // 2)]
@@ -112,11 +120,11 @@ def test_fit_modes(gpu, ref, mode):
             obj = max(obj, abs(at_ref / x["nll"] - 1))
             rel = abs(r["negloglik"] / x["nll"] - 1)
             worst = max(worst, rel)
-            assert rel < 1e-4
-            if rel <= 1e-9:
+            assert rel < max_rel
+            if rel <= on_rel:
                 on += 1
                 for k in ("a", "k2", "k1"):
-                    assert r[k] == pytest.approx(x[k], rel=1e-6, abs=1e-7), k
+                    assert r[k] == pytest.approx(x[k], rel=est_rel, abs=1e-7), k
                 idx = np.where(x["keep"] == 1)[0]
                 np.testing.assert_allclose(post[n][:, idx], x["post"], atol=1e-6)
         print("\nfit %-30s objective at the reference's estimate maxrel %.1e; -logL reached maxrel %.2e; on the reference's "

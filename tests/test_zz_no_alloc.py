@@ -71,3 +71,26 @@ def test_like_noalloc_matches_like_on_shrinking_calls():
         H.like_noalloc(17, d_par.data_ptr(), 1, d_out.data_ptr())
     with pytest.raises(relate_amd.RelateError, match="at most"):
         H.like_noalloc(4560, d_par.data_ptr(), 300, d_out.data_ptr())
+    # After a fit: relate_hip_fit may stage the last live pairs of a block again, side by side (the tail compaction),
+    # and then NO block of P pairs is staged any more -- the call must say so (never compute on other pairs' records);
+    # if the block survived the fit, the values must be those of relate_hip_like.  Either way a relate_hip_like on
+    # the block brings it back.
+    blk = allp[:4560]
+    H.fit(blk)
+    par = _points(len(blk), 3, 9)
+    d_par = torch.from_numpy(par).to(dev)
+    d_out = torch.full((len(blk), 3), -7.0, dtype=torch.float64, device=dev)
+    try:
+        H.like_noalloc(len(blk), d_par.data_ptr(), 3, d_out.data_ptr())
+        intact = True
+    except relate_amd.RelateError as e:
+        intact = False
+        assert "staged" in str(e)
+        assert (d_out.cpu().numpy() == -7.0).all()
+    want = H.like(blk, par)
+    if intact:
+        np.testing.assert_allclose(d_out.cpu().numpy(), want, rtol=1e-10, atol=0)
+    d_out.fill_(-7.0)
+    H.like_noalloc(len(blk), d_par.data_ptr(), 3, d_out.data_ptr())
+    np.testing.assert_allclose(d_out.cpu().numpy(), want, rtol=1e-10, atol=0)
+    print("block intact after the fit: %s" % intact)
