@@ -1914,9 +1914,14 @@ namespace {
 // the size pays a whole block's tail of small launches for a fifth of the pairs).  RELATE_FIT_BLOCK_MAX caps it (tuning).
 size_t fit_block_pairs(relate_hip_t h, long P) {
   size_t lim = pair_block_limit(h, {need_rec(h)});
+  // Long rows: blocks beyond ~16 000 pairs fit no faster per pair, they fit slower -- the launch budget of a round is two
+  // turns of the machine whatever the block holds, so a larger block spreads it over more pairs, fewer points of a pair
+  // sit side by side in a wave, and the sweeps touch more distinct records per step.  Measured at M = 5e5 on 61 440
+  // pairs (tools/fitbench.py): blocks of 12 288 pairs 1 064 pairs/s, 15 360: 1 056, 20 480: 996; 8 192: 965 (round 2).
+  if (h->M >= 150000 && lim > 16384) lim = 16384;
   if (const char *e = getenv("RELATE_FIT_BLOCK_MAX")) {
     long v = atol(e);
-    if (v >= 64 && (size_t)v < lim) lim = (size_t)v;
+    if (v >= 64 && (size_t)v < pair_block_limit(h, {need_rec(h)})) lim = (size_t)v;
   }
   if (P > 0 && (size_t)P > lim) {
     const size_t nb = ((size_t)P + lim - 1) / lim;

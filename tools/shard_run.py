@@ -30,9 +30,13 @@ try:
     with open(os.path.join(tmp, "d.bed"), "wb") as fh:
         fh.write(bytes([0x6C, 0x1B, 0x01])); fh.write(body.tobytes())
     chr_ = np.asarray(chr_)
-    idx = np.arange(M) - np.searchsorted(chr_, chr_)
+    bp = np.rint(np.asarray(pos) * 1e6).astype(np.int64)         # the data set's own positions (Mb) as base pairs
+    for c in np.unique(chr_):                                     # strictly increasing inside a chromosome
+        sel = np.where(chr_ == c)[0]
+        bp[sel] = np.maximum.accumulate(bp[sel] - np.arange(len(sel))) + np.arange(len(sel))
+        assert (np.diff(bp[sel]) > 0).all()
     with open(os.path.join(tmp, "d.bim"), "w") as fh:
-        fh.write("".join("%d\trs%d\t0\t%d\tA\tG\n" % (chr_[s], s, 1000 * idx[s] + 1) for s in range(M)))
+        fh.write("".join("%d\trs%d\t0\t%d\tA\tG\n" % (chr_[s], s, bp[s]) for s in range(M)))
     with open(os.path.join(tmp, "d.fam"), "w") as fh:
         fh.write("".join("F%d I%d 0 0 1 -9\n" % (i, i) for i in range(N)))
     del g, codes, pad, body
@@ -42,11 +46,22 @@ try:
         N, M, time.perf_counter() - t0, RK, NR, b, e, e - b), flush=True)
     env = dict(os.environ, RELATE_FIT_TRACE="1")
     t0 = time.perf_counter()
-    r = subprocess.run([CLI, "-o", OPT, "-plink", "d", "-post", "", "-k", "out.k", "-est", "out.est", "-seed", "4242", "-v", "0",
-                        "-rank", str(RK), "-nranks", str(NR), "-gather", "none", "-gpu", "0"], cwd=tmp, env=env,
-                       capture_output=True, text=True)
+    errf = os.path.join(tmp, "trace.err")
+    with open(errf, "w") as eh, open(os.path.join(tmp, "trace.out"), "w") as oh:
+        pr = subprocess.Popen([CLI, "-o", OPT, "-plink", "d", "-post", "", "-k", "out.k", "-est", "out.est", "-seed", "4242",
+                               "-v", "0", "-rank", str(RK), "-nranks", str(NR), "-gather", "none", "-gpu", "0"], cwd=tmp,
+                              env=env, stdout=oh, stderr=eh)
+        while pr.poll() is None:       # a line a minute: the box takes a silent command for a hung one
+            time.sleep(30)
+            sys.stderr.write("shard run: %.0f s, %d fit blocks done\n" % (
+                time.perf_counter() - t0, sum(l.startswith("fit block") for l in open(errf))))
+            sys.stderr.flush()
     dt = time.perf_counter() - t0
     rss = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 1048576.0
+
+    class R:
+        returncode, stdout, stderr = pr.returncode, open(os.path.join(tmp, "trace.out")).read(), open(errf).read()
+    r = R
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     P = e - b
     print("relateHMM_hip -rank %d -nranks %d -gather none (no .post): %.1f s wall for %d pairs x %d SNPs = %.0f pairs/s = "
@@ -55,6 +70,25 @@ try:
     print("fit blocks (RELATE_FIT_TRACE=1): %d" % len(blocks))
     for l in blocks:
         print("  " + l)
+    # the likelihood launches of the whole run by slot bracket
+    import re
+    rows = []
+    for l in r.stderr.splitlines():
+        m = re.match(r"like launch: (\d+) lanes, (\d+) chunks, ([\d.]+) ms, (\d+) points", l)
+        if m:
+            rows.append((int(m.group(1)), int(m.group(2)), float(m.group(3)), int(m.group(4))))
+    edges = [0, 45056, 65536, 98304, 131072, 196608, 262144, 393216, 10 ** 9]
+    print("likelihood launches: %d, kernel time %.1f s; sweeps by slot bracket:" % (len(rows), sum(x[2] for x in rows) / 1e3))
+    for lo, hi in zip(edges, edges[1:]):
+        sel = [x for x in rows if lo < x[0] <= hi and x[1] == 1]
+        if sel:
+            ms = sum(x[2] for x in sel)
+            print("  %7d..%-7d launches %5d  %9.1f ms  avg %6.1f ms  %6.0f G point-steps/s" % (
+                lo, min(hi, 999999), len(sel), ms, ms / len(sel), sum(x[3] for x in sel) * M / ms / 1e6))
+    sel = [x for x in rows if x[1] > 1]
+    if sel:
+        ms = sum(x[2] for x in sel)
+        print("  cut along the SNP axis: launches %5d  %9.1f ms  %6.0f G point-steps/s" % (len(sel), ms, sum(x[3] for x in sel) * M / ms / 1e6))
     est = np.loadtxt(os.path.join(tmp, "out.est.rank%d" % RK))
     assert len(est) == P
     vals, cnt = np.unique(est[:, -1].astype(int), return_counts=True)
