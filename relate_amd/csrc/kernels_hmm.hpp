@@ -972,16 +972,16 @@ __device__ inline double round_sig4(double x) {
 // posterior_x(s) = fwd_x(s) bwd_x(s) / sum_y fwd_y(s) bwd_y(s): every scale factor cancels.
 // Lanes hold consecutive pairs, whose posterior rows lie 3*M doubles apart: results of kTile SNPs are transposed
 // through LDS so that every pair row is written in whole 128-byte lines.  Workgroup = one wave = 64 pairs of one chunk.
-// worder = 0 (OutT = double): post[p][3][M], rows IBD2, IBD1, IBD0 (the reference's dMatrix).  worder = 1:
-// post[p][rows][M] in the order the .post writer takes them (IBD0, IBD1, IBD2; :3771-3782), the first `rows` of them
+// WROWS = 0 (OutT = double): post[p][3][M], rows IBD2, IBD1, IBD0 (the reference's dMatrix).  WROWS = 1..3:
+// post[p][WROWS][M] in the order the .post writer takes them (IBD0, IBD1, IBD2; :3771-3782), the first WROWS of them
 // -- rows nobody reads are not written (8 B per pair and SNP each); OutT = float: each value the double result rounded
 // once to float.
-template <bool DR, typename OutT>
+template <bool DR, typename OutT, int WROWS>  // WROWS: 0 = the reference's three rows; 1..3 = that many rows in the writer's order
 __global__ void __launch_bounds__(kBwdThreads)
 decode_bwd_kernel(const double *__restrict__ rec, const double *__restrict__ tsh, const int *__restrict__ own, int M, int P, int RP, int col0,
                   const double *__restrict__ params,
                   int nlp, int chunk_len, const double *__restrict__ astart, const double *__restrict__ bend,
-                  TileCkpt ck, OutT *__restrict__ post, int rows, int worder, int sig4) {  // sig4: rows rounded as the .post text
+                  TileCkpt ck, OutT *__restrict__ post, int sig4) {  // sig4: float rows rounded as the .post text
   __shared__ double tile[3][kBwdThreads][kTilePad];
   int bpc = (P + kBwdThreads - 1) / kBwdThreads;
   int c = blockIdx.x / bpc;
@@ -1034,18 +1034,20 @@ decode_bwd_kernel(const double *__restrict__ rec, const double *__restrict__ tsh
       else dec_tile<DR, 2>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
     }
     __syncthreads();
-    // 3 x 64 x kTile values; consecutive threads write consecutive SNPs of one pair row (128-byte pieces)
+    // rows x 64 x kTile values; consecutive threads write consecutive SNPs of one pair row (128-byte pieces).  Output
+    // row rr of a pair is tile row rr (the reference's order) or 2 - rr (the writer's order: IBD0 first); rows that
+    // are not asked for are not visited.
+    constexpr bool WORDER = WROWS > 0;
+    constexpr int nrow = WORDER ? WROWS : 3;
 #pragma unroll 12
-    for (int j = 0; j < 3 * kTile; j++) {
-      int idx = j * kBwdThreads + threadIdx.x;
-      int e = idx % kTile, pr = (idx / kTile) % kBwdThreads, r = idx / (kTile * kBwdThreads);
-      int s = tb + e, pp = pbase + pr;
-      if (!worder) {
-        if (s < te && pp < P) post[((size_t)pp * 3 + r) * M + s] = (OutT)tile[r][pr][e];
-      } else {
-        int rr = 2 - r;
-        if (s < te && pp < P && rr < rows)
-          post[((size_t)pp * rows + rr) * M + s] = (OutT)(sig4 ? round_sig4(tile[r][pr][e]) : tile[r][pr][e]);
+    for (int j = 0; j < nrow * kTile; j++) {
+      const int idx = j * kBwdThreads + threadIdx.x;
+      const int e = idx % kTile, pr = (idx / kTile) % kBwdThreads, rr = idx / (kTile * kBwdThreads);
+      const int s = tb + e, pp = pbase + pr;
+      const double v = tile[WORDER ? 2 - rr : rr][pr][e];
+      if (s < te && pp < P) {
+        if constexpr (sizeof(OutT) == sizeof(double)) post[((size_t)pp * nrow + rr) * M + s] = v;
+        else post[((size_t)pp * nrow + rr) * M + s] = (OutT)(sig4 ? round_sig4(v) : v);
       }
     }
     __syncthreads();

@@ -1302,20 +1302,27 @@ int launch_decode(relate_hip_t h, int p0, int P, int f32_rows = 0, int sig4 = 0,
   }
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
   dim3 bgrid((unsigned)((size_t)((P + kBwdThreads - 1) / kBwdThreads) * nchunk));
-#define LAUNCH_BWD(DRV, T, OUT, ROWS, WORDER)                                                                      \
-  hipLaunchKernelGGL((decode_bwd_kernel<DRV, T>), bgrid, dim3(kBwdThreads), 0, h->stream, rec, h->dTsh.p, h->dPairOwn.p, M, P, RP, p0, \
-                     h->dParams.p, nlp, clen, astart, bend, ck, OUT, ROWS, WORDER, sig4)
+#define LAUNCH_BWD(DRV, T, OUT, WROWS)                                                                              \
+  hipLaunchKernelGGL((decode_bwd_kernel<DRV, T, WROWS>), bgrid, dim3(kBwdThreads), 0, h->stream, rec, h->dTsh.p, h->dPairOwn.p, M, P, RP, p0, \
+                     h->dParams.p, nlp, clen, astart, bend, ck, OUT, sig4)
+#define LAUNCH_BWD_ROWS(DRV, T, OUT, N)       \
+  do {                                        \
+    if ((N) == 1) LAUNCH_BWD(DRV, T, OUT, 1); \
+    else if ((N) == 2) LAUNCH_BWD(DRV, T, OUT, 2); \
+    else LAUNCH_BWD(DRV, T, OUT, 3);          \
+  } while (0)
   if (f32_rows) {
     float *pf = reinterpret_cast<float *>(h->dPost.p);
-    if (dr) LAUNCH_BWD(true, float, pf, f32_rows, 1);
-    else LAUNCH_BWD(false, float, pf, f32_rows, 1);
+    if (dr) LAUNCH_BWD_ROWS(true, float, pf, f32_rows);
+    else LAUNCH_BWD_ROWS(false, float, pf, f32_rows);
   } else if (f64_rows) {
-    if (dr) LAUNCH_BWD(true, double, h->dPost.p, f64_rows, 1);
-    else LAUNCH_BWD(false, double, h->dPost.p, f64_rows, 1);
+    if (dr) LAUNCH_BWD_ROWS(true, double, h->dPost.p, f64_rows);
+    else LAUNCH_BWD_ROWS(false, double, h->dPost.p, f64_rows);
   } else {
-    if (dr) LAUNCH_BWD(true, double, h->dPost.p, 3, 0);
-    else LAUNCH_BWD(false, double, h->dPost.p, 3, 0);
+    if (dr) LAUNCH_BWD(true, double, h->dPost.p, 0);
+    else LAUNCH_BWD(false, double, h->dPost.p, 0);
   }
+#undef LAUNCH_BWD_ROWS
 #undef LAUNCH_BWD
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
@@ -1407,7 +1414,7 @@ int relate_hip_create(relate_hip_t *out, int device_id) {
       ncu = prop.multiProcessorCount;
     long sc = wave_slots(chunk_matrix_kernel<false, false>, 256, ncu);
     long sa = wave_slots(chunk_matrix_kernel<false, true>, 256, ncu);
-    long sb = wave_slots(decode_bwd_kernel<false, double>, kBwdThreads, ncu);
+    long sb = wave_slots(decode_bwd_kernel<false, double, 0>, kBwdThreads, ncu);
     h->slots_like = sc;
     // decode launches (P / 64) waves per chunk in each of its two sweeps
     h->slots_decode = lcm(sa, sb);
