@@ -27,6 +27,16 @@ for it in range(6):
           "(posterior copy-back %.2f GB)" % (P, M, "pinned" if pinned else "pageable", dt * 1e3,
                                              (time.perf_counter() - t1) * 1e3, P * M * (E + 2) / dt,
                                              post.nbytes / 1e9), flush=True)
+pin2 = H.post_buffer(P, 2)
+for it in range(6):
+    blk = allp[(it % 3) * P:(it % 3 + 1) * P]
+    pinned = it >= 3
+    t0 = time.perf_counter()
+    H.like(blk, par)
+    post, _ = H.decode_rows(blk, np.ascontiguousarray(par[:, 0, :]), 2, out=pin2 if pinned else None)
+    dt = time.perf_counter() - t0
+    print("P=%d M=%d double rows IBD0+IBD1 (relate_hip_decode_rows), %s: %.1f ms per step = %.3g HMM steps/s (copy-back "
+          "%.2f GB)" % (P, M, "pinned" if pinned else "pageable", dt * 1e3, P * M * (E + 2) / dt, post.nbytes / 1e9), flush=True)
 pin32 = H.post_buffer(P, 2, np.float32)
 for it in range(3):
     blk = allp[it * P:(it + 1) * P]
