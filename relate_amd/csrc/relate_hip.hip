@@ -744,8 +744,9 @@ struct FitPop {
     int nlanes;             // points of its request that need the GPU
     size_t lane0;           // first lane of this run in the launch
     bool waited;            // its request was held back in the previous round
-    bool taken;             // its request is part of this round's launch
+    bool taken;             // its request is part of the launch being laid out
     bool done;              // fm.done, as of the last consume()
+    signed char flight = -1;  // lane buffer of the launch its request is in (not answered yet), or -1
   };
   int p0 = 0, P = 0;  // pairs [p0, p0 + P) of the staged block
   const relate_opts *o = nullptr;
@@ -760,7 +761,17 @@ struct FitPop {
   std::vector<std::vector<char>> have;
   std::vector<Act> active;
   bool first_round = true, inflight = false, finished = false;
+  // Two launches may be in the air at once (long rows, one population): while one runs, the host feeds the answers of
+  // the previous one to the optimisers and lays out the next from the requests that are pending -- in the steady state
+  // of a block two thirds of the runs wait for the launch budget anyway, so the next launch is known before the current
+  // one ends, and the GPU goes from one to the next without the host in between.  B = the buffer being laid out /
+  // consumed; Bs[k] = lane buffer of flight k; in_air[k] = its launch has been enqueued and not consumed yet.
   LaneBufs *B = nullptr;
+  LaneBufs *Bs[2] = {nullptr, nullptr};
+  bool in_air[2] = {false, false};
+  bool head_in[2] = {false, false};              // the uLike / poLike points ride in that flight
+  bool nothing_idle = false;                     // prepare(): every live run is in the air, nothing to lay out now
+  int nflights() const { return (in_air[0] ? 1 : 0) + (in_air[1] ? 1 : 0); }
   std::vector<int> col;                          // column of every pair in the record block
   int ncols = 0;                                 // columns [p0, p0 + ncols) hold this population's live pairs
   std::function<int(FitPop &, const std::vector<int> &)> restage;  // stages the given pairs into columns p0, p0 + 1, ...
@@ -774,7 +785,9 @@ struct FitPop {
   bool eager = false;
   int eager_forced = -1;
   long seen_first = 0, seen_unsettled = 0;       // pairs whose first wave has been consumed / that needed more runs
-  static constexpr size_t kMaxActiveRuns = 98304;  // ~80 KB of L-BFGS-B state each
+  // ~84 KB of L-BFGS-B state each (12 GB for a block of 16 384 pairs with all 8 restarts alive: what keeps two full
+  // launches' worth of requests pending, so that a second launch can be in the air)
+  static constexpr size_t kMaxActiveRuns = 147456;
   std::vector<std::pair<size_t, size_t>> pads;   // slot gaps [first, second) of the launch being laid out
   std::vector<int> pair_pts;                     // points of each pair taken into the launch being laid out
   bool long_rows = true;                         // rows long enough that the kernels, not the rounds, set the time
@@ -786,6 +799,7 @@ struct FitPop {
   void init(int p0_, int P_, const relate_opts *o_, const FitSpec &S_, const double *starts_, long pair_base_,
             LaneBufs *B_, const int *nsnp) {
     p0 = p0_; P = P_; o = o_; S = S_; starts = starts_; pair_base = pair_base_; B = B_;
+    Bs[0] = B_;
     n = S.nvar();
     R = std::max(1, o->timesToRun);
     mode_bounds(S, lo, hi);
@@ -810,7 +824,12 @@ struct FitPop {
 
   // returns the number of lanes laid out in B, or -1 on a pinned-memory error; sets `finished` when no run is left.
   // Zero lanes with runs left is possible: every requested point short-circuits in its wrapper (infeasible k).
-  long prepare() {
+  // k = the lane buffer to lay the launch out in; second_only_if_full: another launch is in the air, so this one is
+  // laid out only if it fills the launch budget (else -3: wait for the one in the air -- two under-filled launches cost
+  // more than one full one)
+  long prepare(int k = 0, bool second_only_if_full = false) {
+    B = Bs[k];
+    nothing_idle = false;
     auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tq = tnow();
     auto lap = [&](int k) { double t = tnow(); tprep[k] += t - tq; tq = t; };
@@ -882,7 +901,7 @@ struct FitPop {
         // runs started ahead of need for a pair whose rule has stopped meanwhile are dropped unseen
         keep_n = 0;
         for (size_t i = 0; i < active.size(); i++) {
-          if (ms[active[i].pair].finished) drop(active[i].r);
+          if (ms[active[i].pair].finished && active[i].flight < 0) drop(active[i].r);  // (one in the air goes once it is back)
           else active[keep_n++] = active[i];
         }
         active.resize(keep_n);
@@ -899,6 +918,11 @@ struct FitPop {
       finished = true;
       return 0;
     }
+    {
+      bool idle = first_round;
+      for (const Act &a : active) idle = idle || a.flight < 0;
+      if (!idle) { nothing_idle = true; return -3; }
+    }
     // Whole turns of the machine.  A single sweep costs the time of its fullest SIMD, so a launch of 1.1 waves per
     // SIMD costs what one of 2.0 does.  Up to one turn of lanes at two points per lane (131 072 points) a round
     // launches what it has (two-sided sweep: the cost follows the count); beyond, whole turns only, and the rest is
@@ -907,6 +931,7 @@ struct FitPop {
     const long kTurn = 2 * 256L * 4 * 64;
     parallel_for(active.size(), [&](size_t lo_, size_t hi_) {
       for (size_t i = lo_; i < hi_; i++) {  // lanes a run needs: the points its wrapper does not short-circuit
+        if (active[i].flight >= 0) { active[i].nlanes = 0; continue; }  // its request is in the air
         Run *r = active[i].r;
         int nl = 0;
         for (int q = 0; q < r->fm.npts; q++) {
@@ -923,7 +948,7 @@ struct FitPop {
     // of its pair (a launch of 1 300 points over 260 scattered pairs ran HBM-bound at 136 G point-steps/s against
     // ~460 G dense).  Once the live pairs are a quarter of the columns they occupy, their records are staged again
     // side by side (K4 from the genotypes: ~3 us per pair at M = 5e5); finished pairs no longer need theirs.
-    if (!first_round && restage && want > 0 && want < kCompactBelowPoints) {
+    if (!first_round && restage && want > 0 && want < kCompactBelowPoints && nflights() == 0) {
       std::vector<int> live;
       for (int p = 0; p < P; p++)
         if (!ms[p].finished) live.push_back(p);
@@ -944,6 +969,9 @@ struct FitPop {
       else if (all > kTurn && all < kTurn * 9 / 5) budget = kTurn - head;
       else if (all > kTurn / 2 && all < kTurn * 11 / 16) budget = kTurn / 2 - head;
       if (budget < 0) budget = 0;
+      if (second_only_if_full && all < 2 * kTurn) return -3;
+    } else if (second_only_if_full) {
+      return -3;
     }
     // Slots.  A lane of the likelihood kernels may carry nv points of one pair (pick_nv): every pair's points start at
     // a multiple of nv and are padded to one with copies of its last point (values never read); the budget counts
@@ -953,26 +981,27 @@ struct FitPop {
     auto up = [nv](size_t x) { return (x + nv - 1) / nv * nv; };
     long used = 0;
     pair_pts.assign(P, 0);
-    for (Act &a : active) {
-      a.taken = a.waited;
-      if (a.taken) pair_pts[a.pair] += a.nlanes;
-    }
-    for (int p = 0; p < P; p++) used += (long)up(pair_pts[p]);
-    for (Act &a : active) {
-      if (a.taken) continue;
-      const long delta = (long)up(pair_pts[a.pair] + a.nlanes) - (long)up(pair_pts[a.pair]);
-      if (used + delta <= budget) {
-        a.taken = true;
-        used += delta;
-        pair_pts[a.pair] += a.nlanes;
+    // requests held back before go first (in pair order, so the list is worked through and none starves), then the
+    // others; both within the budget -- a launch above two turns of the machine falls into a bracket that costs half
+    // as much again (285 000 slots: 180 ms against 127 ms for 262 144)
+    for (Act &a : active) a.taken = false;
+    for (int pass = 0; pass < 2; pass++)
+      for (Act &a : active) {
+        if (a.flight >= 0 || a.taken || a.waited != (pass == 0)) continue;
+        const long delta = (long)up(pair_pts[a.pair] + a.nlanes) - (long)up(pair_pts[a.pair]);
+        if (used + delta <= budget) {
+          a.taken = true;
+          used += delta;
+          pair_pts[a.pair] += a.nlanes;
+        }
       }
-    }
     B->nv = nv;
-    ul = (int)up(2);
+    if (first_round) ul = (int)up(2);
     size_t nl_total = first_round ? (size_t)ul * P : 0;
     pads.clear();
     int prev_pair = -1;
     for (Act &a : active) {
+      if (a.flight >= 0) continue;
       a.waited = !a.taken;
       if (a.taken && a.nlanes > 0 && a.pair != prev_pair) {
         if (nl_total % nv) pads.push_back({nl_total, up(nl_total)});
@@ -989,9 +1018,13 @@ struct FitPop {
     lap(5);
     B->nl = (int)nl_total;
     B->npoints = first_round ? 2L * P : 0;
-    for (const Act &a : active)
-      if (a.taken) B->npoints += a.nlanes;
+    for (Act &a : active)
+      if (a.taken) {
+        B->npoints += a.nlanes;
+        a.flight = (signed char)k;
+      }
     B->wanted = want + (first_round ? 2L * P : 0);
+    head_in[k] = first_round;
     if (first_round)
       for (int p = 0; p < P; p++)
         for (int j = 0; j < ul; j++) {
@@ -1022,23 +1055,26 @@ struct FitPop {
         for (int c = 0; c < 3; c++) B->par[3 * at + c] = B->par[3 * (g.first - 1) + c];
       }
     lap(6);
+    first_round = false;  // (the head rides in this launch: head_in[k])
     return (long)nl_total;
   }
   double tprep[7] = {0, 0, 0, 0, 0, 0, 0};  // seconds by phase of prepare(): start runs, retire, map points, restage, select, pinned buffers, lay out
 
-  void consume(relate_fit *out) {  // out: records of the staged block
+  void consume(relate_fit *out, int k = 0) {  // out: records of the staged block; k: the flight whose values are in
+    B = Bs[k];
     const double *val = B->val;
-    if (first_round) {
+    if (head_in[k]) {
       for (int p = 0; p < P; p++) {
         out[p0 + p].uLike = val[(size_t)ul * p];
         out[p0 + p].poLike = val[(size_t)ul * p + 1];
       }
-      first_round = false;
+      head_in[k] = false;
     }
     std::atomic<bool> bad_seen{false};
     parallel_for(active.size(), [&](size_t lo_, size_t hi_) {
       for (size_t i = lo_; i < hi_; i++) {
-        if (!active[i].taken) continue;
+        if (active[i].flight != k) continue;
+        active[i].flight = -1;
         Run *r = active[i].r;
         double v[7];
         bool bad = false;
@@ -1160,6 +1196,62 @@ int fit_block(relate_hip_t h, int P, long pair_base, const double *starts, relat
   }
   double t_prep = 0, t_cons = 0, t_wait = 0;  // host seconds by phase (RELATE_FIT_TRACE)
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  int rc = 0;
+  // One population, long rows: two launches in the air (FitPop::Bs).  RELATE_FIT_FLIGHTS=1 keeps one (tests, tuning).
+  static const int max_flights = [] { const char *e = getenv("RELATE_FIT_FLIGHTS"); return e && atoi(e) == 1 ? 1 : 2; }();
+  if (npop == 1 && max_flights == 2 && pop[0].long_rows) {
+    FitPop &F = pop[0];
+    F.Bs[1] = &h->lanebufs[1];
+    int fifo[2] = {-1, -1}, nq = 0;  // flights in the air, oldest first
+    // lays a launch out in buffer k and enqueues it; 1 = enqueued, 0 = nothing to launch now (or the block is finished)
+    auto launch = [&](int k, bool only_if_full) -> int {
+      for (;;) {
+        const double t0 = now();
+        long nl = F.prepare(k, only_if_full);
+        t_prep += now() - t0;
+        if (nl == -2) { rc = RELATE_E_HIP; return 0; }
+        if (nl == -1) { rc = fail(h, RELATE_E_NOMEM, "host memory for the optimiser runs or the likelihood lanes"); return 0; }
+        if (nl == -3 || F.finished) return 0;
+        if (nl > 0) {
+          rc = like_enqueue(h, P, *F.Bs[k]);
+          if (rc) return 0;
+          F.in_air[k] = true;
+          fifo[nq++] = k;
+          return 1;
+        }
+        F.consume(out, k);  // nothing to evaluate on the GPU: the wrappers answered every point of these runs themselves
+      }
+    };
+    // A second launch beside one in the air is only made when it fills the budget; prepare() finds that out, but a
+    // prepare() that ends in "not full" is 3-5 ms of host work for nothing, so it is only tried when the requests known
+    // to be pending could fill one: what the last layout left behind plus (after a flight has come back) about what
+    // that flight carried.
+    const long kFull = 2L * 2 * 256 * 4 * 64;
+    auto left_behind = [&](int k) { return F.Bs[k]->wanted - F.Bs[k]->npoints; };
+    launch(0, false);
+    if (!rc && nq == 1 && left_behind(0) >= kFull) launch(1, true);
+    while (nq > 0 && !rc) {
+      const int k = fifo[0];
+      double t0 = now();
+      rc = like_wait(h, *F.Bs[k]);
+      t_wait += now() - t0;
+      if (rc) break;
+      fifo[0] = fifo[1];
+      nq--;
+      F.in_air[k] = false;
+      const long came_back = F.Bs[k]->npoints;
+      t0 = now();
+      F.consume(out, k);
+      t_cons += now() - t0;
+      if (nq > 0) {  // the other flight is in the air: this one goes up again only as a full launch
+        const int other = fifo[0];
+        if (left_behind(other) + came_back >= kFull) launch(k, true);
+      } else {
+        launch(k, false);
+        if (!rc && nq == 1 && !F.finished && left_behind(k) >= kFull) launch(k == 0 ? 1 : 0, true);
+      }
+    }
+  } else {
   auto start = [&](FitPop &F) -> int {
     F.inflight = false;
     for (;;) {
@@ -1176,7 +1268,6 @@ int fit_block(relate_hip_t h, int P, long pair_base, const double *starts, relat
       F.consume(out);  // nothing to evaluate on the GPU this round: the wrappers answered every point themselves
     }
   };
-  int rc = 0;
   for (int k = 0; k < npop && !rc; k++) rc = start(pop[k]);
   for (bool any = true; any && !rc;) {
     any = false;
@@ -1193,6 +1284,7 @@ int fit_block(relate_hip_t h, int P, long pair_base, const double *starts, relat
       t_cons += now() - t0;
       rc = start(F);
     }
+  }
   }
   if (rc) {
     (void)hipStreamSynchronize(h->stream);  // nothing of a failed block stays queued on its buffers
@@ -1921,10 +2013,9 @@ namespace {
 // the size pays a whole block's tail of small launches for a fifth of the pairs).  RELATE_FIT_BLOCK_MAX caps it (tuning).
 size_t fit_block_pairs(relate_hip_t h, long P) {
   size_t lim = pair_block_limit(h, {need_rec(h)});
-  // Long rows: blocks beyond ~16 000 pairs fit no faster per pair, they fit slower -- the launch budget of a round is two
-  // turns of the machine whatever the block holds, so a larger block spreads it over more pairs, fewer points of a pair
-  // sit side by side in a wave, and the sweeps touch more distinct records per step.  Measured at M = 5e5 on 61 440
-  // pairs (tools/fitbench.py): blocks of 12 288 pairs 1 064 pairs/s, 15 360: 1 056, 20 480: 996; 8 192: 965 (round 2).
+  // Long rows: blocks beyond ~16 000 pairs fit no faster per pair (measured at M = 5e5 on 61 440 pairs,
+  // tools/fitbench.py: blocks of 12 288, 15 360 and 20 480 pairs all at 1 064 - 1 070 pairs/s), and every live run holds
+  // 84 KB of optimiser state on the host (all 8 restarts of 16 384 pairs: 11 GB), so the block is capped there.
   if (h->M >= 150000 && lim > 16384) lim = 16384;
   if (const char *e = getenv("RELATE_FIT_BLOCK_MAX")) {
     long v = atol(e);

@@ -32,6 +32,8 @@ if os.environ.get("RELATE_FIT_BREAKDOWN_CHILD") != "1":
     if r.returncode:
         sys.stderr.write(r.stdout[-3000:] + r.stderr[-3000:])
         raise SystemExit(r.returncode)
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        open(os.path.join(ROOT, "gpurun_out", "fit_trace_raw.txt"), "w").write(r.stderr)
     head = [l for l in r.stdout.splitlines() if l.startswith("fit:")][-1]
     wall, M, P = float(re.search(r"wall ([\d.]+) s", head).group(1)), int(re.search(r"M (\d+)", head).group(1)), a.pairs
     rows, blk, mark = [], None, False
