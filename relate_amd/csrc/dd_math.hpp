@@ -12,7 +12,7 @@
 #pragma once
 #include <cmath>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define DDM_HD __host__ __device__
 #else
 #define DDM_HD
