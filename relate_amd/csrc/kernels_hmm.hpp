@@ -904,9 +904,10 @@ static constexpr int kTile = 16;
 static constexpr int kTilePad = kTile + 1;
 static constexpr int kBwdThreads = 64;  // one wave per workgroup: 13.5 KiB of LDS each
 
-template <bool DR, int TIER>
+// tile row j holds IBD0 (j = 0), IBD1, IBD2; only the first NR are kept (rows the caller does not write never reach LDS)
+template <bool DR, int TIER, int NR>
 __device__ __forceinline__ void dec_tile(const LaneC &C, const Rec (&R)[kTile], double f0, double f1, double f2, int tb, int te,
-                                double &b0, double &b1, double &b2, double (&tile)[3][kBwdThreads][kTilePad]) {
+                                double &b0, double &b1, double &b2, double (&tile)[NR][kBwdThreads][kTilePad]) {
   constexpr int NG = kTile / kGroup;
   double G[NG][3];
   {
@@ -943,9 +944,9 @@ __device__ __forceinline__ void dec_tile(const LaneC &C, const Rec (&R)[kTile], 
       inv = inv * __builtin_fma(-sum, inv, 2.0);
       bool dr = rec_dropped(r);
       const int e = g * kGroup + u;
-      tile[2][threadIdx.x][e] = dr ? -1.0 : p0 * inv;  // row2 = IBD0
-      tile[1][threadIdx.x][e] = dr ? -1.0 : p1 * inv;
-      tile[0][threadIdx.x][e] = dr ? -1.0 : p2 * inv;  // row0 = IBD2
+      tile[0][threadIdx.x][e] = dr ? -1.0 : p0 * inv;
+      if constexpr (NR > 1) tile[1][threadIdx.x][e] = dr ? -1.0 : p1 * inv;
+      if constexpr (NR > 2) tile[2][threadIdx.x][e] = dr ? -1.0 : p2 * inv;
       bwd_step<DR, TIER>(C, r, b0, b1, b2);
       norm_fast(b0, b1, b2);
     }
@@ -982,7 +983,9 @@ decode_bwd_kernel(const double *__restrict__ rec, const double *__restrict__ tsh
                   const double *__restrict__ params,
                   int nlp, int chunk_len, const double *__restrict__ astart, const double *__restrict__ bend,
                   TileCkpt ck, OutT *__restrict__ post, int sig4) {  // sig4: float rows rounded as the .post text
-  __shared__ double tile[3][kBwdThreads][kTilePad];
+  constexpr bool WORDER = WROWS > 0;
+  constexpr int nrow = WORDER ? WROWS : 3;
+  __shared__ double tile[nrow][kBwdThreads][kTilePad];
   int bpc = (P + kBwdThreads - 1) / kBwdThreads;
   int c = blockIdx.x / bpc;
   int pbase = (blockIdx.x % bpc) * kBwdThreads;
@@ -1026,25 +1029,23 @@ decode_bwd_kernel(const double *__restrict__ rec, const double *__restrict__ tsh
     if (col.general && own_distance(R)) {
       Rec E[kTile];
       rec_lane_all(R, E);
-      dec_tile<DR, 2>(C, E, f0, f1, f2, tb, te, b0, b1, b2, tile);
+      dec_tile<DR, 2, nrow>(C, E, f0, f1, f2, tb, te, b0, b1, b2, tile);
     } else {
       int tier = group_tier<kTile>(C, R);
-      if (tier == 0) dec_tile<DR, 0>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
-      else if (tier == 1) dec_tile<DR, 1>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
-      else dec_tile<DR, 2>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
+      if (tier == 0) dec_tile<DR, 0, nrow>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
+      else if (tier == 1) dec_tile<DR, 1, nrow>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
+      else dec_tile<DR, 2, nrow>(C, R, f0, f1, f2, tb, te, b0, b1, b2, tile);
     }
     __syncthreads();
     // rows x 64 x kTile values; consecutive threads write consecutive SNPs of one pair row (128-byte pieces).  Output
     // row rr of a pair is tile row rr (the reference's order) or 2 - rr (the writer's order: IBD0 first); rows that
     // are not asked for are not visited.
-    constexpr bool WORDER = WROWS > 0;
-    constexpr int nrow = WORDER ? WROWS : 3;
 #pragma unroll 12
     for (int j = 0; j < nrow * kTile; j++) {
       const int idx = j * kBwdThreads + threadIdx.x;
       const int e = idx % kTile, pr = (idx / kTile) % kBwdThreads, rr = idx / (kTile * kBwdThreads);
       const int s = tb + e, pp = pbase + pr;
-      const double v = tile[WORDER ? 2 - rr : rr][pr][e];
+      const double v = tile[WORDER ? rr : 2 - rr][pr][e];  // the reference's order is IBD2 first
       if (s < te && pp < P) {
         if constexpr (sizeof(OutT) == sizeof(double)) post[((size_t)pp * nrow + rr) * M + s] = v;
         else post[((size_t)pp * nrow + rr) * M + s] = (OutT)(sig4 ? round_sig4(v) : v);

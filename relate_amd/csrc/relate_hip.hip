@@ -191,7 +191,8 @@ struct relate_hip_ctx {
   double timings[4] = {0, 0, 0, 0};
   double like_stats[6] = {0, 0, 0, 0, 0, 0};  // relate_hip_last_like_stats
   int last_chunks[2] = {1, 1};  // SNP-axis chunks of the last like / decode launch
-  long slots_like = 2048, slots_decode = 6144;  // resident waves of the chunked sweeps (set at create)
+  long slots_like = 2048;                             // resident waves of the chunked sweeps (set at create)
+  long slots_decode[4] = {6144, 6144, 6144, 6144};    // by the rows pass B writes (0 = the reference's three): its LDS tile sets its occupancy
   ncclComm_t comm = nullptr;  // relate_hip_gather: one communicator per handle, made at the first gather
   int comm_rank = -1, comm_n = 0;
   long gather_seq = 0;        // gathers issued on this handle (names the rendezvous files of each)
@@ -200,6 +201,12 @@ struct relate_hip_ctx {
   unsigned char *scratch_dev = nullptr;  // device address of `scratch` on this handle's GPU (relate_hip_like_noalloc)
   long single_sweep_lanes = 45056;              // launches below this many lanes are cut along the SNP axis (pick_chunks)
   RunArena run_arena;
+  // rolling refills of a long fit (FitPop::roll): pinned pair lists and kept-SNP counts of the segments being staged, and
+  // the event behind their staging work
+  int32_t *refill_pairs = nullptr;
+  int *refill_nsnp = nullptr;
+  size_t refill_cap = 0;
+  hipEvent_t refill_ev = nullptr;
   int fit_eager = -1;  // what the previous fit of this data set saw: 1 = first waves of restarts rarely settle a pair (FitPop::eager)
 };
 
@@ -367,23 +374,27 @@ inline MemNeed need_path(relate_hip_t h, bool want) {
 
 // K4: n pairs into columns [col0, col0 + n) of a record buffer whose padded pair count is RP (full: dRecV, else dRec
 // together with its per-pair factors and kept-SNP counts).  Returns with the work done and the counts on the host.
-int stage_cols(relate_hip_t h, const int32_t *pairs, int n, int col0, int RP, bool full) {
-  for (int p = 0; p < n; p++) {
+int check_pairs(relate_hip_t h, const int32_t *pairs, long n) {
+  for (long p = 0; p < n; p++) {
     int a = pairs[2 * p], b = pairs[2 * p + 1];
     if (a < 0 || a >= h->N || b < 0 || b >= h->N)
       return fail(h, RELATE_E_ARG, "pair index out of range (the data set has " + std::to_string(h->N) + " individuals)");
   }
+  return 0;
+}
+// the staging work queued on the library's stream, nothing waited for; d_pairs = where the pair list goes on the device
+// (a list still being read by an earlier launch of the queue must not be overwritten: callers that queue several
+// stagings give each its own part of dPairs)
+int stage_cols_enqueue(relate_hip_t h, const int32_t *pairs, int n, int col0, int RP, bool full, int32_t *d_pairs) {
   DBuf<double> &R = full ? h->dRecV : h->dRec;
   const int words = 2, chunk = 64;  // SNPs per staging thread: 64 either way
   const int nruns = h->winMode ? (h->Wt + words - 1) / words : (h->M + chunk - 1) / chunk;
-  HIPCHK(h, h->dPairs.ensure((size_t)2 * n));
-  HIPCHK(h, hipMemcpyAsync(h->dPairs.p, pairs, sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  HIPCHK(h, hipMemcpyAsync(d_pairs, pairs, sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice, h->stream));
   if (h->winMode) {
     unsigned grid = (unsigned)((size_t)nruns * ((n + 255) / 256));
 #define STAGE_WIN(FULL)                                                                                              \
   hipLaunchKernelGGL(stage_pairs_win_kernel<FULL>, dim3(grid), dim3(256), 0, h->stream, h->dGt.p, h->M, h->Wt,         \
-                     h->dPairs.p, n, words, h->dPos.p, h->dTab1.p, h->dTabD.p, h->dMea.p, h->dChoose.p, h->dOrder.p, \
+                     d_pairs, n, words, h->dPos.p, h->dTab1.p, h->dTabD.p, h->dMea.p, h->dChoose.p, h->dOrder.p, \
                      h->useLD, h->o.back, h->back2, R.p, RP, col0, h->dScM.p, h->dScE.p, h->dScN.p)
     if (full) STAGE_WIN(true);
     else STAGE_WIN(false);
@@ -393,7 +404,7 @@ int stage_cols(relate_hip_t h, const int32_t *pairs, int n, int col0, int RP, bo
     const unsigned ggrid = (unsigned)((size_t)nruns * ((n + 63) / 64));
 #define STAGE_GEN(FULL)                                                                                               \
   hipLaunchKernelGGL(stage_pairs_kernel<FULL>, dim3(ggrid), dim3(64), 0, h->stream, h->dG.p, h->dGt.p, h->Wt, h->M,   \
-                     h->W, h->dPairs.p, n, h->dPos.p, h->dTab1.p, h->dTabL.p, h->dChoose.p, h->dMea.p,                \
+                     h->W, d_pairs, n, h->dPos.p, h->dTab1.p, h->dTabL.p, h->dChoose.p, h->dMea.p,                    \
                      h->dPBA.p, h->dPbA.p, h->dPBa.p, h->dPba.p, h->useLD, h->o.back, h->back2, h->o.epsilon, R.p,    \
                      RP, col0, h->dScM.p, h->dScE.p, h->dScN.p)
     if (full) STAGE_GEN(true);
@@ -409,11 +420,20 @@ int stage_cols(relate_hip_t h, const int32_t *pairs, int n, int col0, int RP, bo
     if (h->nBnd > 0) {  // runs of dropped SNPs across a chromosome break (kernels_emis.hpp); after the counts: a pair
                         // without a kept SNP would have every thread of it scan the whole row for one
       hipLaunchKernelGGL(boundary_fixup_kernel, dim3(blocks_for((long)n * h->nBnd, 256)), dim3(256), 0, h->stream,
-                         h->dG.p, h->M, h->W, h->dPairs.p, n, h->dBnd.p, h->nBnd, h->dPos.p, R.p, RP, col0,
+                         h->dG.p, h->M, h->W, d_pairs, n, h->dBnd.p, h->nBnd, h->dPos.p, R.p, RP, col0,
                          h->dPairOwn.p, h->dNsnp.p);
       HIPCHK(h, hipGetLastError());
     }
   }
+  return 0;
+}
+int stage_cols(relate_hip_t h, const int32_t *pairs, int n, int col0, int RP, bool full) {
+  int rc = check_pairs(h, pairs, n);
+  if (rc) return rc;
+  HIPCHK(h, h->dPairs.ensure((size_t)2 * n));
+  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  rc = stage_cols_enqueue(h, pairs, n, col0, RP, full, h->dPairs.p);
+  if (rc) return rc;
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
   if (!full)
     HIPCHK(h, hipMemcpyAsync(h->h_nsnp.data() + col0, h->dNsnp.p + col0, sizeof(int) * n, hipMemcpyDeviceToHost, h->stream));
@@ -1359,7 +1379,14 @@ int copy_to_host(relate_hip_t h, void *dst, const void *src, size_t bytes) {
 int launch_decode(relate_hip_t h, int p0, int P, int f32_rows = 0, int sig4 = 0, int f64_rows = 0) {
   const int M = h->M;
   int nchunk, clen;
-  pick_chunks(M, P, h->single_sweep_lanes, 256, h->slots_decode, 1, &nchunk, &clen);
+  pick_chunks(M, P, h->single_sweep_lanes, 256, h->slots_decode[f32_rows ? f32_rows : f64_rows], 1, &nchunk, &clen);
+  if (const char *e = getenv("RELATE_DECODE_CHUNKS")) {  // tuning experiments
+    const int want = atoi(e);
+    if (want >= 1 && want <= std::max(1, M / 512)) {
+      clen = ((M + want - 1) / want + 15) / 16 * 16;
+      nchunk = (M + clen - 1) / clen;
+    }
+  }
   h->last_chunks[1] = nchunk;
   const bool dr = h->o.double_recom != 0;
   const int nlp = pad256(P);
@@ -1506,10 +1533,12 @@ int relate_hip_create(relate_hip_t *out, int device_id) {
       ncu = prop.multiProcessorCount;
     long sc = wave_slots(chunk_matrix_kernel<false, false>, 256, ncu);
     long sa = wave_slots(chunk_matrix_kernel<false, true>, 256, ncu);
-    long sb = wave_slots(decode_bwd_kernel<false, double, 0>, kBwdThreads, ncu);
     h->slots_like = sc;
     // decode launches (P / 64) waves per chunk in each of its two sweeps
-    h->slots_decode = lcm(sa, sb);
+    h->slots_decode[0] = lcm(sa, wave_slots(decode_bwd_kernel<false, double, 0>, kBwdThreads, ncu));
+    h->slots_decode[1] = lcm(sa, wave_slots(decode_bwd_kernel<false, double, 1>, kBwdThreads, ncu));
+    h->slots_decode[2] = lcm(sa, wave_slots(decode_bwd_kernel<false, double, 2>, kBwdThreads, ncu));
+    h->slots_decode[3] = lcm(sa, wave_slots(decode_bwd_kernel<false, double, 3>, kBwdThreads, ncu));
   }
   {
     // the no-alloc entry point's scratch: every GPU holds its own copy of the array at its own address

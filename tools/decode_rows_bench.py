@@ -15,9 +15,10 @@ M = H.init_globals(geno, pos, chr_, opt)
 del geno
 blk = synth.all_pairs(2000)[:P]
 par = np.ascontiguousarray(bench.eval_points(P, 1)[:, 0, :])
-for rows in (0, 3, 2, 1, 0, 2):
+ROWS = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (0, 3, 2, 1, 0, 2)
+for rows in ROWS:
     H.bench_decode(blk, par, 1, rows=rows)
     f, b = H.bench_decode(blk, par, 3, rows=rows)
     nb = 3 if rows == 0 else rows
-    print("rows %d (%s): pass A %.2f ms, pass B %.2f ms = %.2f TB/s on %.2f B per pair and SNP" % (
-        rows, "reference order" if rows == 0 else "writer order", f, b, (16 + 5.25 + 8 * nb) * P * M / b / 1e9, 16 + 5.25 + 8 * nb), flush=True)
+    print("rows %d (%s), %d chunks: pass A %.2f ms, pass B %.2f ms = %.2f TB/s on %.2f B per pair and SNP" % (
+        rows, "reference order" if rows == 0 else "writer order", H.last_chunks()[1], f, b, (16 + 5.25 + 8 * nb) * P * M / b / 1e9, 16 + 5.25 + 8 * nb), flush=True)

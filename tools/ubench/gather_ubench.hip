@@ -96,6 +96,78 @@ __global__ void __launch_bounds__(64) bwd(const double *__restrict__ rec, const 
   }
 }
 
+
+// Variant 2: codes + the SNP's dominant-depth slice of the table (81 entries x 16 B) staged through LDS by a workgroup of
+// NW waves (64 x NW pairs of one SNP chunk share a tile of 16 slices = 20.7 KB); lanes whose code sits on another depth
+// (a missing genotype in the pair's window) gather that record from the table in global memory.
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) bwd_lds(const uint16_t *__restrict__ codes, const double2 *__restrict__ tab, int M, int P,
+                                                   int RP, int chunk_len, int nwork, double *__restrict__ post) {
+  constexpr int NT = 64 * NW, kSlice = 81, kPer = (kTile * kSlice + NT - 1) / NT;
+  __shared__ double2 lt[kTile * kSlice];
+  int bpc = (P + NT - 1) / NT;
+  int c = blockIdx.x / bpc;
+  int p = (blockIdx.x % bpc) * NT + threadIdx.x;
+  const bool live = p < P;
+  if (!live) p = P - 1;
+  int sb = c * chunk_len, se = min(M, sb + chunk_len);
+  double b0 = 1, b1 = 1, b2 = 1;
+  double2 R[kTile], T[kPer];
+  uint4 C0, C1;
+  auto load_codes = [&](int tb, uint4 &a, uint4 &b) {
+    const uint4 *q = (const uint4 *)(codes + ((size_t)(tb >> 3) * RP + p) * 8);
+    a = q[0];
+    b = q[(size_t)RP];
+  };
+  auto load_table = [&](int tb) {  // this thread's share of the 16 slices of tile tb
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+      int e = threadIdx.x + j * NT;
+      int u = e / kSlice, k = e - u * kSlice;
+      if (e < kTile * kSlice) T[j] = tab[(size_t)(tb + u) * kEntries + 10 + ((tb + u) % 5) * kSlice + k];
+    }
+  };
+  int tb0 = (se - 1) & ~(kTile - 1);
+  load_codes(tb0, C0, C1);
+  load_table(tb0);
+  for (int tb = tb0; tb >= sb; tb -= kTile) {
+    __syncthreads();  // everyone is done with the previous tile's slices
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+      int e = threadIdx.x + j * NT;
+      if (e < kTile * kSlice) lt[e] = T[j];
+    }
+    __syncthreads();
+    const unsigned w[8] = {C0.x, C0.y, C0.z, C0.w, C1.x, C1.y, C1.z, C1.w};
+#pragma unroll
+    for (int u = 0; u < kTile; u++) {
+      unsigned code = (w[u >> 1] >> (16 * (u & 1))) & 0xffffu;
+      int k = (int)code - 10 - ((tb + u) % 5) * kSlice;
+      if (k >= 0 && k < kSlice) R[u] = lt[u * kSlice + k];
+      else R[u] = tab[(size_t)(tb + u) * kEntries + code];
+    }
+    int tn = max(tb - kTile, sb);
+    load_codes(tn, C0, C1);
+    load_table(tn);
+    double o0[kTile], o1[kTile];
+#pragma unroll
+    for (int u = kTile - 1; u >= 0; u--) {
+      work(R[u].x, R[u].y, b0, b1, b2, nwork);
+      o0[u] = b0 + b2;
+      o1[u] = b1;
+    }
+    if (live) {
+#pragma unroll
+      for (int u = 0; u < kTile; u++) {
+        if (tb + u < se) {
+          post[(size_t)(tb + u) * P + p] = o0[u];
+          post[(size_t)M * P + (size_t)(tb + u) * P + p] = o1[u];
+        }
+      }
+    }
+  }
+}
+
 int main(int argc, char **argv) {
   int P = argc > 1 ? atoi(argv[1]) : 5120, M = argc > 2 ? atoi(argv[2]) : 250000, nchunk = argc > 3 ? atoi(argv[3]) : 46;
   int nwork = argc > 4 ? atoi(argv[4]) : 150, skew = argc > 5 ? atoi(argv[5]) : 1;
@@ -133,18 +205,20 @@ int main(int argc, char **argv) {
   dim3 grid((unsigned)((size_t)((P + 63) / 64) * nchunk));
   printf("P %d, M %d, chunks %d (len %d), work %d FMA per SNP, %s combinations; records %.1f GB, codes %.1f GB, table %.1f GB\n", P, M,
          nchunk, clen, nwork, skew ? "skewed" : "uniform", nrec * 8 / 1e9, ncode * 2 / 1e9, ntab * 16 / 1e9);
-  for (int v = 0; v < 2; v++) {
+  for (int v = 0; v < 4; v++) {
     for (int rep = 0; rep < 3; rep++) {
       CHK(hipEventRecord(e0));
       if (v == 0) hipLaunchKernelGGL(bwd<0>, grid, dim3(64), 0, 0, rec, codes, tab, M, P, RP, clen, nwork, post);
-      else hipLaunchKernelGGL(bwd<1>, grid, dim3(64), 0, 0, rec, codes, tab, M, P, RP, clen, nwork, post);
+      else if (v == 1) hipLaunchKernelGGL(bwd<1>, grid, dim3(64), 0, 0, rec, codes, tab, M, P, RP, clen, nwork, post);
+      else if (v == 2) hipLaunchKernelGGL(bwd_lds<4>, dim3((unsigned)((size_t)((P + 255) / 256) * nchunk)), dim3(256), 0, 0, codes, tab, M, P, RP, clen, nwork, post);
+      else hipLaunchKernelGGL(bwd_lds<2>, dim3((unsigned)((size_t)((P + 127) / 128) * nchunk)), dim3(128), 0, 0, codes, tab, M, P, RP, clen, nwork, post);
       CHK(hipEventRecord(e1));
       CHK(hipDeviceSynchronize());
       float ms;
       CHK(hipEventElapsedTime(&ms, e0, e1));
       double units = (double)P * M;
       if (rep)
-        printf("variant %d (%s): %8.3f ms  %.1f G pair*SNP/s  (x 2 for M = 5e5: %.1f ms)\n", v, v ? "codes + table gather" : "16-byte records",
+        printf("variant %d (%s): %8.3f ms  %.1f G pair*SNP/s  (x 2 for M = 5e5: %.1f ms)\n", v, v == 0 ? "16-byte records" : v == 1 ? "codes + table gather" : v == 2 ? "codes + LDS slices, 256 pairs" : "codes + LDS slices, 128 pairs",
                ms, units / ms / 1e6, ms * 5e5 / M);
     }
   }
