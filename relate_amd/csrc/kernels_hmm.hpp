@@ -937,8 +937,14 @@ __device__ __forceinline__ void dec_tile(const LaneC &C, const Rec (&R)[kTile], 
     for (int u = kGroup - 1; u >= 0; u--) {
       if (hb + u >= te) continue;  // uniform
       const Rec &r = R[g * kGroup + u];
-      double p0 = F[u][0] * b0, p1 = F[u][1] * b1, p2 = F[u][2] * b2;
-      double sum = (p0 + p1) + p2;
+      double p0, p1, p2, sum;
+      {
+        // no contraction here: with fewer rows kept the products feed only the sum, and a product fused into the sum
+        // in one instantiation but not in another would make the rows differ in the last bit between them
+#pragma clang fp contract(off)
+        p0 = F[u][0] * b0; p1 = F[u][1] * b1; p2 = F[u][2] * b2;
+        sum = (p0 + p1) + p2;
+      }
       double inv = __builtin_amdgcn_rcp(sum);
       inv = inv * __builtin_fma(-sum, inv, 2.0);
       inv = inv * __builtin_fma(-sum, inv, 2.0);
