@@ -400,10 +400,12 @@ def main():
                        "decode_fwd": "chunk_matrix_kernel<false, true>",
                        "decode_bwd": "decode_bwd_kernel"}
         traffic = pmc_traffic(P, M, E)
+        bwd_key = "relate::decode_bwd_kernel<false, double, %d>" % ROWS
         tkey = {"stage": ["relate::stage_pairs_win_kernel<false>"], "like": ["relate::chunk_matrix_kernel<false, false>"],
-                "decode_fwd": ["relate::chunk_matrix_kernel<false, true>"],
-                "decode_bwd": ["relate::decode_bwd_kernel<false, double>"]}[dom]
-        tr = sum(traffic[k] for k in tkey) if traffic and all(k in traffic for k in tkey) else None
+                "decode_fwd": ["relate::chunk_matrix_kernel<false, true>"], "decode_bwd": [bwd_key]}[dom]
+        tr_dom = sum(traffic[k] for k in tkey) if traffic and all(k in traffic for k in tkey) else None
+        k6_keys = ["relate::chunk_matrix_kernel<false, true>", "relate::decode_combine_kernel", bwd_key]  # the launches `achieved` is over
+        tr = sum(traffic[k] for k in k6_keys) if traffic and all(k in traffic for k in k6_keys) else None
         like_steps_s = P * M * E / (per["like"] * 1e-3)
         valu = VALU_PER_STEP[3 if lc > 1 else 1]
         dec_ms = per["decode_fwd"] + per["decode_bwd"]
@@ -430,7 +432,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "K6 decode = chunk_matrix_kernel<false, true> + decode_combine_kernel + "
                                                    "decode_bwd_kernel (dominant launch: %s)" % kernel_name[dom],
                          "achieved": survey_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": survey_gbs / HBM_PEAK_GBS,
-                         "traffic": tr,
+                         "traffic": tr, "traffic_dominant_launch": tr_dom,
                          "algorithmic_bytes": SURVEY_BYTES["decode"] * units,
                          "algorithmic_bytes_per_pair_snp": SURVEY_BYTES["decode"],
                          "decode_ms": dec_ms,
@@ -440,9 +442,9 @@ def main():
                          "note": "achieved / frac price the whole K6 (both passes) at SURVEY 8(d)'s algorithmic bytes, "
                                  "0.5 + 8 x rows per pair and SNP with rows = %d, over the HIP-event time of its launches; "
                                  "frac_design = the dominant launch of the step among the HBM-bound ones on this design's own "
-                                 "bytes (materialised 16 B records, tile checkpoints); traffic = HBM bytes per launch of that "
-                                 "kernel from the committed PMC passes (profiles/pmc_traffic.json), null if they were taken on "
-                                 "another configuration.  The likelihood kernels are FP64-VALU-bound: roofline_fp64" % ROWS},
+                                 "bytes (materialised 16 B records, tile checkpoints); traffic = HBM bytes of one K6 (its three "
+                                 "launches; traffic_dominant_launch: of the dominant one) from the committed PMC passes "
+                                 "(profiles/pmc_traffic.json), null if they were taken on another configuration.  The likelihood kernels are FP64-VALU-bound: roofline_fp64" % ROWS},
             "roofline_fp64": {"kernel": kernel_name["like"], "valu_insts_per_lane_step": valu,
                               "achieved": like_steps_s * valu / 1e12, "peak": FP64_LANE_OPS_PEAK / 1e12,
                               "unit": "T lane-instructions/s", "frac": like_steps_s * valu / FP64_LANE_OPS_PEAK,
