@@ -278,7 +278,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--inds", type=int, default=2000)
     ap.add_argument("--snps", type=int, default=500000)
-    ap.add_argument("--pairs", type=int, default=5120, help="pairs per block per GPU (decode holds ~6000 at M = 5e5)")
+    ap.add_argument("--pairs", type=int, default=12288,
+                    help="pairs per block per GPU: 12 288 x 5e5 SNPs = 98 GB of records + 98 GB of posterior rows + 32 GB of "
+                         "tile checkpoints of the 288 GB; E x pairs = 61 440 lanes, enough for the likelihood to run as whole "
+                         "sweeps (rounds 1 and 2 took 5 120, whose 25 600 lanes had to be cut along the SNP axis)")
     ap.add_argument("--points", type=int, default=5, help="evaluation points per pair per like launch")
     ap.add_argument("--no-cpu", action="store_true", help="bench line only: no cpu_baseline, no fit leg")
     ap.add_argument("--no-fit", action="store_true")
@@ -395,13 +398,16 @@ def main():
         gbs = {k: BYTES[k] * units / (per[k] * 1e-3) / 1e9 for k in per}
         # the dominant kernel of the step among the HBM-bound ones (the likelihood group is FP64-VALU-bound: roofline_fp64)
         dom = max((k for k in per if k != "like"), key=per.get)
+        nv_like = 2 if E % 2 == 0 else 1          # points of one pair per lane (nv_for_points in relate_hip.hip)
+        two_sided = lc == 1 and P * E // nv_like <= (98304 if nv_like == 1 else 65536)   # launch_like's route
         kernel_name = {"stage": "stage_pairs_win_kernel",
-                       "like": "chunk_matrix_kernel<false, false>" if lc > 1 else "like_kernel",
+                       "like": "chunk_matrix_kernel<false, false>" if lc > 1 else
+                               ("like_halves_kernel + like_join_kernel (two-sided sweep)" if two_sided else "like_kernel"),
                        "decode_fwd": "chunk_matrix_kernel<false, true>",
                        "decode_bwd": "decode_bwd_kernel"}
         traffic = pmc_traffic(P, M, E)
         bwd_key = "relate::decode_bwd_kernel<false, double, %d>" % ROWS
-        tkey = {"stage": ["relate::stage_pairs_win_kernel<false>"], "like": ["relate::chunk_matrix_kernel<false, false>"],
+        tkey = {"stage": ["relate::stage_pairs_win_kernel<false>"], "like": ["relate::chunk_matrix_kernel<false, false>"] if lc > 1 else ["relate::like_halves_kernel<false, 4, 1>"],
                 "decode_fwd": ["relate::chunk_matrix_kernel<false, true>"], "decode_bwd": [bwd_key]}[dom]
         tr_dom = sum(traffic[k] for k in tkey) if traffic and all(k in traffic for k in tkey) else None
         k6_keys = ["relate::chunk_matrix_kernel<false, true>", "relate::decode_combine_kernel", bwd_key]  # the launches `achieved` is over
@@ -458,8 +464,18 @@ def main():
             "kernels_hbm_frac": {k: v / HBM_PEAK_GBS for k, v in gbs.items()},
             "setup_s": {"synthetic_data": t_gen, "load_precalc": t_pre},
         }
+        if world == 1 and not args.no_cpu:
+            # The legs below are not part of `value`.  The step's buffers (posterior rows, checkpoints: 130 GB) are of no use
+            # to them and the fit wants the memory for records: the handle is closed and the legs run on a fresh one.
+            H.close()
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu and not args.no_linkage:
             line["linkage_mode"] = linkage_leg(local, args.inds, args.snps, all_pairs, min(args.linkage_pairs, len(all_pairs)))
+        if world == 1 and not args.no_cpu and (not args.no_fit or not args.no_baseline):
+            geno, pos, chr_, _ = synth.make_dataset(args.inds, args.snps, device="cuda:%d" % local)
+            H = relate_amd.Relate(local)
+            assert H.init_globals(geno, pos, chr_, opt) == M
+            del geno
         if world == 1 and not args.no_cpu and not args.no_fit:
             line["fit"] = fit_leg(H, mine, min(args.fit_pairs, len(mine)), M)
             line["end_to_end_pair_snp_per_s"] = line["fit"]["pair_snp_per_s"]
