@@ -1382,7 +1382,7 @@ int launch_decode(relate_hip_t h, int p0, int P, int f32_rows = 0, int sig4 = 0,
   pick_chunks(M, P, h->single_sweep_lanes, 256, h->slots_decode[f32_rows ? f32_rows : f64_rows], 1, &nchunk, &clen);
   if (const char *e = getenv("RELATE_DECODE_CHUNKS")) {  // tuning experiments
     const int want = atoi(e);
-    if (want >= 1 && want <= std::max(1, M / 512)) {
+    if (want >= 1 && want <= std::max(1, M / 32)) {  // (chunks are whole tiles of 16 SNPs; short ones are only slow)
       clen = ((M + want - 1) / want + 15) / 16 * 16;
       nchunk = (M + clen - 1) / clen;
     }

@@ -208,6 +208,34 @@ def test_decode_rows_returns_exactly_the_rows_of_decode(gpu, prepared):
                 assert ta.raw[r * stride:r * stride + la[r]] == tb.raw[r * stride:r * stride + lb[r]]
 
 
+def test_decode_does_not_depend_on_how_the_snp_axis_is_cut(gpu, prepared, monkeypatch):
+    """K6 cuts the SNP axis into chunks (pass A: a 3 x 3 product and tile checkpoints per chunk; combine; pass B from the
+    chunk's boundary vectors).  The posteriors are a property of the pair and its parameters, not of the cut: one chunk
+    (the plain forward-backward), the library's own choice and two odd cuts must agree to rounding, dropped SNPs and SNP
+    counts exactly, under both transition models."""
+    b = pc.golden()["blocks"][0]
+    pairs = [(0, 1), (5, 12), (2, 9), (3, 50), (100, 103), (7, 8), (11, 60)]
+    par = np.array([(0.05, 0.2, 0.3), (0.1, 0.0, 0.4), (0.03, 0.0, 1.0), (0.07, 0.4, 0.0), (0.09, 0.1, 0.1), (0.02, 0.3, 0.6),
+                    (0.9, 0.05, 0.5)])
+    for dr in (0, 1):
+        _init(gpu, prepared, b, double_recom=dr)
+        monkeypatch.setenv("RELATE_DECODE_CHUNKS", "1")
+        one, _, ns1 = gpu.decode(pairs, par)
+        assert gpu.last_chunks()[1] == 1
+        for cut in (None, "3", "7"):
+            if cut is None:
+                monkeypatch.delenv("RELATE_DECODE_CHUNKS")
+            else:
+                monkeypatch.setenv("RELATE_DECODE_CHUNKS", cut)
+            got, _, ns = gpu.decode(pairs, par)
+            if cut is not None:
+                assert 1 < gpu.last_chunks()[1] <= int(cut)
+            assert np.array_equal(ns, ns1) and np.array_equal(got == -1, one == -1)
+            np.testing.assert_allclose(got, one, rtol=0, atol=1e-12)
+            rows, _ = gpu.decode_rows(pairs, par, rows=2)
+            np.testing.assert_allclose(rows[:, 0, :], one[:, 2, :], rtol=0, atol=1e-12)
+
+
 def test_fit_with_explicit_starts_equals_seeded_run(gpu, prepared):
     import relate_amd
     G = pc.golden()
