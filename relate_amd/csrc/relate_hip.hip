@@ -2849,6 +2849,7 @@ extern "C" int relate_hip_gather(relate_hip_t h, const relate_fit *mine, int64_t
     int seen = 0;
     if (N.CommCount && N.CommCount(h->comm, &seen) == ncclSuccess) h->gather_ranks_seen = seen;
   }
+  if (P_total == 0) return RELATE_OK;  // nothing to exchange (every rank knows it: P_total is the same on all of them)
   // equal counts per rank: shards are padded to the longest one (they differ by at most one record)
   const size_t per = (size_t)((P_total + nranks - 1) / nranks) * sizeof(relate_fit);
   HIPCHK(h, h->dGatherS.ensure(per));
